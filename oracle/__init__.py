@@ -1,0 +1,1 @@
+"""CPU oracles (test infrastructure only; never imported by the product package)."""
