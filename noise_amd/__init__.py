@@ -1,0 +1,5 @@
+"""MI355X-native speech-enhancement hot path (STFT -> denoiser -> iSTFT, mixing) behind the
+reference's module interfaces.  Kernels live in libnoise_hip.so (hand-written HIP for gfx950)."""
+from . import _lib  # noqa: F401  (fails loudly when the kernel library is missing)
+from .stft import STFT  # noqa: F401
+from .mixer import segmental_snr_mixer, activitydetector  # noqa: F401

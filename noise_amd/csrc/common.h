@@ -1,0 +1,82 @@
+// Shared host/device helpers for the noise_hip kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#define NOISE_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing: every entry point returns 0 on success; the text of the last failure
+// on the calling thread is available through noise_last_error().
+void noise_set_error(const char* fmt, ...);
+
+#define NOISE_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      noise_set_error(__VA_ARGS__);         \
+      return -1;                            \
+    }                                       \
+  } while (0)
+
+#define NOISE_CHECK_LAUNCH(name)                                                   \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      noise_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return (int)e__;                                                             \
+    }                                                                              \
+  } while (0)
+
+static inline int noise_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Memory-bound elementwise/reduction kernels: cap the grid and grid-stride the rest.
+static inline int noise_grid(long work_items, int per_block, int cap = 2048) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ---- lazily normalised activations --------------------------------------------------------
+// A convolution writes its RAW output y; BatchNorm (+ReLU6) is applied by whoever reads it:
+//     a[p][c] = act(scale[c] * y[p][c] + shift[c])
+// `coef` points at [scale(C) | shift(C) | mean(C) | invstd(C)] or is null for a plain tensor.
+struct LazySrc {
+  const float* y;
+  const float* coef;
+  int relu6;
+};
+
+// Gradient w.r.t. a raw conv output, reconstructed on the fly:
+//     dy[p][c] = s[c]*dz[p][c] + alpha[c]*y[p][c] + beta[c]
+// where dz is the (ReLU6-masked) gradient w.r.t. the BatchNorm output.  `coef3` points at
+// [s(C) | alpha(C) | beta(C)] or is null when dy == dz (no BatchNorm after the conv).
+struct LazyGrad {
+  const float* dz;
+  const float* y;
+  const float* coef3;
+};
+
+#ifdef __HIPCC__
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif

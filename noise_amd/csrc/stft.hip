@@ -1,0 +1,307 @@
+// STFT / iSTFT for MI355X (gfx950): windowed real DFT and its inverse as fp32-MFMA tile products.
+//
+// Replaces train/models.py:460-475 (STFT.forward: reflect pad + strided conv1d with the windowed
+// DFT basis + log-magnitude / atan2) and :477-495 (STFT.inverse: exp/cos/sin recombination,
+// conv_transpose1d overlap-add, window-envelope scaling, crop, clamp).  The same frame-product
+// kernel, run with the inverse basis, is the adjoint needed for the iSTFT backward pass.
+//
+// Layout: waveforms [B][L]; spectra [B][F][T] (T innermost, as the reference's (B,1,F,T)).
+// One workgroup = 64 frames of one clip.  The clip samples the tile touches are staged once in
+// LDS (coalesced, reflect-padded by index mirroring); frames are read from that staging with a
+// row pitch of hop+1 so the 32 frames of an MFMA column tile hit 32 different banks.
+// v_mfma_f32_32x32x2_f32 keeps the arithmetic exact fp32 (a k-ordered fmaf chain).
+#include "common.h"
+
+namespace {
+
+struct StftDims {
+  int B, L, T, n_fft, hop, F, Rpad, Lout;
+};
+
+constexpr int STFT_TF = 64;  // frames per workgroup
+
+// MODE 0: forward  -> log-magnitude, phase, per-clip max|log-magnitude|
+// MODE 1: adjoint of the iSTFT: sig = dL/d(wave_out); writes dL/d(log-magnitude)
+template <int MODE, int NT>
+__global__ __launch_bounds__(256) void stft_frames_kernel(
+    const float* __restrict__ sig, const float* __restrict__ basisT, float* __restrict__ out0,
+    float* __restrict__ out1, unsigned* __restrict__ absmax_bits, const float* __restrict__ wave_out,
+    const float* __restrict__ wsum, const float* __restrict__ logmag, const float* __restrict__ phase,
+    StftDims d) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * STFT_TF;
+  const int hop = d.hop, n_fft = d.n_fft, pitch = hop + 1;
+  const int R = n_fft / hop;
+  const int nS = (STFT_TF - 1) * hop + n_fft;
+  const int half = n_fft / 2;
+
+  // ---- stage the samples of this tile (index in the padded signal = t0*hop + i)
+  for (int i = tid; i < nS; i += 256) {
+    int s = t0 * hop + i - half;
+    float v;
+    if (MODE == 0) {
+      if (s < 0) s = -s;
+      if (s >= d.L) s = 2 * (d.L - 1) - s;
+      s = min(max(s, 0), d.L - 1);  // only reached by frames past T (never stored)
+      v = sig[(size_t)b * d.L + s];
+    } else {
+      v = 0.f;
+      if (s >= 0 && s < d.Lout) {
+        size_t o = (size_t)b * d.Lout + s;
+        float w = wave_out[o];
+        v = (w > -1.f && w < 1.f) ? sig[o] * wsum[s + half] : 0.f;
+      }
+    }
+    lds[i + i / hop] = v;
+  }
+  __syncthreads();
+
+  const int nRT = d.Rpad >> 5;
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int r = 0; r < NT; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+
+  const float* bas = basisT + n;
+  for (int c = 0; c < R; ++c) {
+#pragma unroll 4
+    for (int kq = 0; kq < hop; kq += 2) {
+      const int kk = c * hop + kq + h;
+      const float b0 = lds[n * pitch + kk + c];
+      const float b1 = lds[(n + 32) * pitch + kk + c];
+      const float* arow = bas + (size_t)kk * d.Rpad;
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        const int rt = wave + 4 * r;
+        if (rt < nRT) {
+          const float a = arow[rt * 32];
+          acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[r][0], 0, 0, 0);
+          acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[r][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: rows are interleaved (2f = Re, 2f+1 = Im); a lane holds rows 8g+4h..+3
+  float amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < NT; ++r) {
+    const int rt = wave + 4 * r;
+    if (rt >= nRT) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int t = t0 + 32 * c + n;
+      if (t >= d.T) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int f = (rt * 32 + 8 * g + 4 * h) / 2 + q;
+          if (f >= d.F) continue;
+          const float re = acc[r][c][4 * g + 2 * q], im = acc[r][c][4 * g + 2 * q + 1];
+          const size_t o = ((size_t)b * d.F + f) * d.T + t;
+          if (MODE == 0) {
+            const float lm = logf(fmaxf(sqrtf(re * re + im * im), 1e-3f));
+            out0[o] = lm;
+            out1[o] = atan2f(im, re);
+            amax = fmaxf(amax, fabsf(lm));
+          } else {
+            float sn, cs;
+            sincosf(phase[o], &sn, &cs);
+            out0[o] = expf(logmag[o]) * (cs * re + sn * im);
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 0 && absmax_bits != nullptr) {
+    amax = wave_reduce_max(amax);
+    if (lane == 0) atomicMax(absmax_bits + b, __float_as_uint(amax));
+  }
+}
+
+constexpr int ISTFT_TF = 32;  // frames per workgroup (incl. the R-1 halo frames)
+
+template <int NT>
+__global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ logmag,
+                                                    const float* __restrict__ phase,
+                                                    const float* __restrict__ inv_basis,
+                                                    const float* __restrict__ wsum,
+                                                    const float* __restrict__ vad_logit,
+                                                    float* __restrict__ out, StftDims d) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int hop = d.hop, n_fft = d.n_fft, F = d.F;
+  const int R = n_fft / hop;
+  const int TFo = ISTFT_TF - (R - 1);
+  const int q0 = blockIdx.x * TFo;        // first output hop of this tile
+  const int tstart = q0 - (R - 1);        // first frame of this tile
+
+  // ---- stage z = [mag*cos ; mag*sin] for the tile's 32 frames: zs[(2f+part)*32 + tl]
+  for (int i = tid; i < F * 32; i += 256) {
+    const int f = i >> 5, tl = i & 31, t = tstart + tl;
+    float zr = 0.f, zi = 0.f;
+    if (t >= 0 && t < d.T) {
+      const size_t o = ((size_t)b * F + f) * d.T + t;
+      const float m = expf(logmag[o]);
+      float sn, cs;
+      sincosf(phase[o], &sn, &cs);
+      zr = m * cs;
+      zi = m * sn;
+    }
+    lds[(2 * f) * 32 + tl] = zr;
+    lds[(2 * f + 1) * 32 + tl] = zi;
+  }
+  __syncthreads();
+
+  const int nNT = n_fft >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int r = 0; r < NT; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+  const float* bas = inv_basis + (size_t)h * F * n_fft + n;
+#pragma unroll 4
+  for (int f = 0; f < F; ++f) {
+    const float bv = lds[(2 * f + h) * 32 + n];
+    const float* arow = bas + (size_t)f * n_fft;
+#pragma unroll
+    for (int r = 0; r < NT; ++r) {
+      const int nt = wave + 4 * r;
+      if (nt < nNT) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[nt * 32], bv, acc[r], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- time-domain frames to LDS: ft[tl][sample], pitch n_fft+1
+  const int fp = n_fft + 1;
+#pragma unroll
+  for (int r = 0; r < NT; ++r) {
+    const int nt = wave + 4 * r;
+    if (nt >= nNT) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      lds[n * fp + row] = acc[r][e];
+    }
+  }
+  __syncthreads();
+
+  // ---- atomic-free overlap-add: every output sample gathers its R frames
+  float gate = 1.f;
+  if (vad_logit != nullptr) gate = 1.f / (1.f + expf(-1e4f * vad_logit[b]));
+  const int half = n_fft / 2;
+  for (int i = tid; i < TFo * hop; i += 256) {
+    const int jj = i / hop, m = i - jj * hop;
+    const int s = (q0 + jj) * hop + m;
+    const int so = s - half;
+    if (so < 0 || so >= d.Lout) continue;
+    float y = 0.f;
+    for (int r = 0; r < R; ++r) y += lds[(jj + R - 1 - r) * fp + r * hop + m];
+    y *= wsum[s];
+    y = fminf(fmaxf(y, -1.f), 1.f) * gate;
+    out[(size_t)b * d.Lout + so] = y;
+  }
+}
+
+int check_dims(const char* who, int B, int L, int n_fft, int hop) {
+  NOISE_REQUIRE(B > 0 && L > 0, "%s: empty batch (B=%d, L=%d)", who, B, L);
+  NOISE_REQUIRE(n_fft >= 64 && n_fft % 32 == 0 && n_fft <= 1024, "%s: n_fft=%d unsupported (multiple of 32 in [64,1024])", who, n_fft);
+  NOISE_REQUIRE(hop > 0 && hop % 2 == 0 && n_fft % hop == 0, "%s: hop=%d must be even and divide n_fft=%d", who, hop, n_fft);
+  NOISE_REQUIRE(L > n_fft / 2, "%s: L=%d too short for reflect padding of %d", who, L, n_fft / 2);
+  return 0;
+}
+
+template <int MODE>
+int launch_frames(const float* sig, const float* basisT, float* out0, float* out1, unsigned* absmax,
+                  const float* wave_out, const float* wsum, const float* logmag, const float* phase,
+                  StftDims d, hipStream_t st) {
+  const int nRT = d.Rpad / 32;
+  const int per_wave = (nRT + 3) / 4;
+  const int nS = (STFT_TF - 1) * d.hop + d.n_fft;
+  const size_t smem = (size_t)(nS + nS / d.hop + 1) * sizeof(float);
+  dim3 grid(noise_cdiv(d.T, STFT_TF), d.B);
+  if (per_wave <= 3) {
+    hipLaunchKernelGGL((stft_frames_kernel<MODE, 3>), grid, dim3(256), smem, st, sig, basisT, out0, out1, absmax,
+                       wave_out, wsum, logmag, phase, d);
+  } else if (per_wave <= 5) {
+    hipLaunchKernelGGL((stft_frames_kernel<MODE, 5>), grid, dim3(256), smem, st, sig, basisT, out0, out1, absmax,
+                       wave_out, wsum, logmag, phase, d);
+  } else {
+    hipLaunchKernelGGL((stft_frames_kernel<MODE, 9>), grid, dim3(256), smem, st, sig, basisT, out0, out1, absmax,
+                       wave_out, wsum, logmag, phase, d);
+  }
+  return 0;
+}
+
+}  // namespace
+
+NOISE_EXPORT int noise_stft_rpad(int n_fft) { return ((2 * (n_fft / 2 + 1) + 31) / 32) * 32; }
+
+NOISE_EXPORT int noise_stft_fwd(const float* wave, const float* basisT, float* logmag, float* phase,
+                                float* absmax, int B, int L, int n_fft, int hop, void* stream) {
+  if (check_dims("noise_stft_fwd", B, L, n_fft, hop)) return -1;
+  NOISE_REQUIRE(wave && basisT && logmag && phase, "noise_stft_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  StftDims d{B, L, L / hop + 1, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (L / hop)};
+  if (absmax) {
+    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * B, st);
+    NOISE_REQUIRE(e == hipSuccess, "noise_stft_fwd: memset failed: %s", hipGetErrorString(e));
+  }
+  launch_frames<0>(wave, basisT, logmag, phase, (unsigned*)absmax, nullptr, nullptr, nullptr, nullptr, d, st);
+  NOISE_CHECK_LAUNCH("noise_stft_fwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_istft_fwd(const float* logmag, const float* phase, const float* inv_basis,
+                                 const float* window_sum, const float* vad_logit, float* wave_out, int B, int T,
+                                 int n_fft, int hop, void* stream) {
+  NOISE_REQUIRE(B > 0 && T > 0, "noise_istft_fwd: empty batch (B=%d, T=%d)", B, T);
+  if (check_dims("noise_istft_fwd", B, n_fft, n_fft, hop)) return -1;
+  NOISE_REQUIRE(logmag && phase && inv_basis && window_sum && wave_out, "noise_istft_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int F = n_fft / 2 + 1, R = n_fft / hop;
+  NOISE_REQUIRE(R < ISTFT_TF, "noise_istft_fwd: n_fft/hop=%d too large", R);
+  StftDims d{B, 0, T, n_fft, hop, F, 0, hop * (T - 1)};
+  NOISE_REQUIRE(d.Lout > 0, "noise_istft_fwd: need at least 2 frames");
+  const int TFo = ISTFT_TF - (R - 1);
+  const int hops = T - 1 + R;
+  dim3 grid(noise_cdiv(hops, TFo), B);
+  const size_t smem = (size_t)(2 * F) * 32 * sizeof(float);
+  const int per_wave = (n_fft / 32 + 3) / 4;
+  if (per_wave <= 3) {
+    hipLaunchKernelGGL((istft_kernel<3>), grid, dim3(256), smem, st, logmag, phase, inv_basis, window_sum, vad_logit, wave_out, d);
+  } else if (per_wave <= 4) {
+    hipLaunchKernelGGL((istft_kernel<4>), grid, dim3(256), smem, st, logmag, phase, inv_basis, window_sum, vad_logit, wave_out, d);
+  } else {
+    hipLaunchKernelGGL((istft_kernel<8>), grid, dim3(256), smem, st, logmag, phase, inv_basis, window_sum, vad_logit, wave_out, d);
+  }
+  NOISE_CHECK_LAUNCH("noise_istft_fwd");
+  return 0;
+}
+
+// Adjoint of noise_istft_fwd w.r.t. the log-magnitude input (the phase receives no gradient:
+// it is taken from the noisy input).  d_wave [B][hop*(T-1)], inv_basisT laid out like the
+// forward basisT ([n_fft][Rpad], row 2f = Re f, row 2f+1 = Im f).
+NOISE_EXPORT int noise_istft_bwd(const float* d_wave, const float* wave_out, const float* logmag,
+                                 const float* phase, const float* inv_basisT, const float* window_sum,
+                                 float* d_logmag, int B, int T, int n_fft, int hop, void* stream) {
+  NOISE_REQUIRE(B > 0 && T > 1, "noise_istft_bwd: empty batch (B=%d, T=%d)", B, T);
+  if (check_dims("noise_istft_bwd", B, n_fft, n_fft, hop)) return -1;
+  NOISE_REQUIRE(d_wave && wave_out && logmag && phase && inv_basisT && window_sum && d_logmag,
+                "noise_istft_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  StftDims d{B, 0, T, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (T - 1)};
+  launch_frames<1>(d_wave, inv_basisT, d_logmag, nullptr, nullptr, wave_out, window_sum, logmag, phase, d, st);
+  NOISE_CHECK_LAUNCH("noise_istft_bwd");
+  return 0;
+}

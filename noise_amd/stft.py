@@ -1,0 +1,152 @@
+"""`STFT` with the reference's interface (train/models.py:410-548), computed by HIP kernels.
+
+Same constructor, same three registered buffers (`forward_basis`, `inverse_basis`,
+`window_sum`, so reference checkpoints load), same `forward` / `inverse` contracts:
+
+    forward(waveform (B,1,1,L))            -> log_magnitude (B,1,F,T), phase (B,F,T)
+    inverse(log_magnitude, phase)          -> waveform (B,1,1,hop*(T-1)) clamped to [-1,1]
+
+`inverse` is differentiable w.r.t. `log_magnitude` (the only gradient the training step needs:
+the phase comes from the noisy input).  There is no CPU path: tensors must live on the GPU.
+"""
+import numpy as np
+import torch
+from scipy.signal import get_window
+
+from . import _lib
+
+
+def _pad_center(w, size):
+    lpad = (size - len(w)) // 2
+    return np.pad(w, (lpad, size - len(w) - lpad))
+
+
+def window_sumsquare(window, n_frames, hop_length, win_length, n_fft):
+    """Sum-of-squared-windows envelope (train/models.py:497-548), accumulated in float32 in frame
+    order like the reference's loop, but vectorised over frames."""
+    R = -(-n_fft // hop_length)
+    win_sq = _pad_center(get_window(window, win_length, fftbins=True) ** 2, n_fft)
+    win_sq = np.pad(win_sq, (0, R * hop_length - n_fft))
+    Q = n_frames - 1 + R
+    env = np.zeros((Q, hop_length), dtype=np.float32)
+    for r in range(R - 1, -1, -1):  # increasing frame index t = q - r
+        seg = win_sq[r * hop_length:(r + 1) * hop_length]
+        lo, hi = r, min(Q, n_frames + r)
+        env[lo:hi] = (env[lo:hi].astype(np.float64) + seg).astype(np.float32)
+    return env.reshape(-1)[: n_fft + hop_length * (n_frames - 1)]
+
+
+def interleaved_transposed(basis, n_fft):
+    """(2F, n_fft) [Re rows ; Im rows] -> (n_fft, Rpad) with column 2f = Re f, 2f+1 = Im f, zero padded
+    to a multiple of 32: the layout the frame-product kernel reads (coalesced along the rows it owns)."""
+    F = n_fft // 2 + 1
+    rpad = ((2 * F + 31) // 32) * 32
+    out = torch.zeros(n_fft, rpad, dtype=basis.dtype, device=basis.device)
+    out[:, 0:2 * F:2] = basis[:F].t()
+    out[:, 1:2 * F:2] = basis[F:].t()
+    return out.contiguous()
+
+
+class _InverseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_magnitude, phase, stft):
+        out = stft._inverse_raw(log_magnitude, phase, None)
+        ctx.stft = stft
+        ctx.save_for_backward(log_magnitude, phase, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lm, ph, out = ctx.saved_tensors
+        return ctx.stft._inverse_bwd(grad_out, out, lm, ph), None, None
+
+
+class STFT(torch.nn.Module):
+    def __init__(self, max_frames, n_fft, hop_length, win_length, window):
+        super().__init__()
+        self.max_frames = max_frames
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.win_length = win_length
+        self.window = window
+        self.scale = n_fft / hop_length
+        self.pad_amount = n_fft // 2
+        self.cutoff = n_fft // 2 + 1
+
+        dft = np.fft.fft(np.eye(n_fft))
+        basis = np.vstack([dft[: self.cutoff].real, dft[: self.cutoff].imag])
+        forward_basis = torch.from_numpy(basis).float()
+        inverse_basis = torch.from_numpy(np.linalg.pinv(self.scale * basis).T).float()
+        if window is not None:
+            assert n_fft >= win_length
+            w = torch.from_numpy(_pad_center(get_window(window, win_length, fftbins=True), n_fft)).float()
+            forward_basis = forward_basis * w
+            inverse_basis = inverse_basis * w
+            env = window_sumsquare(window, max_frames, hop_length, win_length, n_fft)
+        else:
+            env = np.ones(n_fft + hop_length * (max_frames - 1), dtype=np.float32)
+        env[env == 0] = 1
+        window_sum = torch.from_numpy((self.scale / env).astype(np.float32))
+        if window is None:  # the reference multiplies by window_sum only when a window is set
+            window_sum = torch.ones_like(window_sum)
+
+        self.register_buffer("forward_basis", forward_basis[:, None, :].contiguous())
+        self.register_buffer("inverse_basis", inverse_basis[:, None, :].contiguous())
+        self.register_buffer("window_sum", window_sum)
+        self._derived = None  # (key, forward basisT, inverse basisT) rebuilt when buffers move/change
+
+    # -- kernel-side layouts of the two bases, derived lazily from the registered buffers
+    def _bases(self):
+        fb, ib = self.forward_basis, self.inverse_basis
+        key = (fb.data_ptr(), fb._version, ib.data_ptr(), ib._version)
+        if self._derived is None or self._derived[0] != key:
+            self._derived = (key, interleaved_transposed(fb[:, 0, :], self.n_fft),
+                             interleaved_transposed(ib[:, 0, :], self.n_fft))
+        return self._derived[1], self._derived[2]
+
+    def num_frames(self, L):
+        return L // self.hop_length + 1
+
+    def forward(self, waveform, return_absmax=False):
+        _lib.require_cuda(waveform, self.forward_basis)
+        B = waveform.shape[0]
+        L = waveform.shape[-1]
+        wave = waveform.reshape(B, L).contiguous().float()
+        T = self.num_frames(L)
+        basisT, _ = self._bases()
+        logmag = torch.empty(B, 1, self.cutoff, T, device=wave.device, dtype=torch.float32)
+        phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32)
+        absmax = torch.empty(B, device=wave.device, dtype=torch.float32) if return_absmax else None
+        _lib.call("noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisT), _lib.ptr(logmag), _lib.ptr(phase),
+                  _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream())
+        if return_absmax:
+            return logmag, phase, absmax
+        return logmag, phase
+
+    def _inverse_raw(self, log_magnitude, phase, vad_logit):
+        _lib.require_cuda(log_magnitude, phase, self.inverse_basis)
+        B, _, F, T = log_magnitude.shape
+        lm = log_magnitude.contiguous().float()
+        ph = phase.contiguous().float()
+        n_out = self.hop_length * (T - 1)
+        assert self.n_fft + self.hop_length * (T - 1) <= self.window_sum.numel(), "more frames than max_frames"
+        out = torch.empty(B, 1, 1, n_out, device=lm.device, dtype=torch.float32)
+        _lib.call("noise_istft_fwd", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(self.inverse_basis),
+                  _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft,
+                  self.hop_length, _lib.stream())
+        return out
+
+    def _inverse_bwd(self, grad_out, out, log_magnitude, phase):
+        B, _, F, T = log_magnitude.shape
+        _, inv_basisT = self._bases()
+        g = grad_out.contiguous().float()
+        d_lm = torch.empty_like(log_magnitude, dtype=torch.float32)
+        _lib.call("noise_istft_bwd", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
+                  _lib.ptr(phase.contiguous()), _lib.ptr(inv_basisT), _lib.ptr(self.window_sum), _lib.ptr(d_lm),
+                  B, T, self.n_fft, self.hop_length, _lib.stream())
+        return d_lm
+
+    def inverse(self, log_magnitude, phase):
+        if torch.is_grad_enabled() and log_magnitude.requires_grad:
+            return _InverseFn.apply(log_magnitude, phase, self)
+        return self._inverse_raw(log_magnitude, phase, None)
