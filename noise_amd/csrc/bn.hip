@@ -1,0 +1,160 @@
+// BatchNorm bookkeeping for lazily normalised activations (train/models.py: every nn.BatchNorm2d
+// created through Conv2dNormActivation / InvertedResidual, :371-397, :1151-1159).
+//
+// forward  : per-workgroup (sum, sum-of-squares) partials written by the conv kernels are folded
+//            into [scale | shift | mean | invstd] and the running statistics are updated
+//            (momentum 0.1, unbiased running variance, num_batches_tracked += 1).
+// backward : one pass over (g1 [+ g2], y) applies the ReLU6 mask, writes dz and the partial sums
+//            of dz and dz*xhat; the finalize kernel turns them into dgamma, dbeta and the three
+//            per-channel coefficients with which consumers rebuild dL/dy = s*dz + alpha*y + beta.
+#include "lazy.h"
+
+namespace {
+
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ slab, int nrows, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                       long long* __restrict__ num_batches_tracked, float momentum, float eps,
+                                       float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrows; ++r) {
+    s1 += (double)slab[(size_t)r * 2 * C + c];
+    s2 += (double)slab[(size_t)r * 2 * C + C + c];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  coef[c] = sc;
+  coef[C + c] = beta[c] - (float)mean * sc;
+  coef[2 * C + c] = (float)mean;
+  coef[3 * C + c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+}
+
+__global__ void bn_coef_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                    float eps, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(running_var[c] + eps);
+  const float sc = gamma[c] * invstd;
+  coef[c] = sc;
+  coef[C + c] = beta[c] - running_mean[c] * sc;
+  coef[2 * C + c] = running_mean[c];
+  coef[3 * C + c] = invstd;
+}
+
+// dz = (g1 + g2) * [0 < scale*y+shift < 6]   (mask only when relu6);  partials of sum dz, sum dz*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                            const float* __restrict__ y, const float* __restrict__ coef,
+                                                            int relu6, int C, long npix, float* __restrict__ dz,
+                                                            float* __restrict__ slab) {
+  extern __shared__ float red[];
+  const int CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (pl < PPB) {
+    const int c = 4 * cg;
+    const float4 sc = ld4(coef + c), sh = ld4(coef + C + c), mean = ld4(coef + 2 * C + c), istd = ld4(coef + 3 * C + c);
+    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
+      const size_t off = (size_t)pix * C + c;
+      float4 g = ld4(g1 + off);
+      if (g2) g = g + ld4(g2 + off);
+      const float4 yv = ld4(y + off);
+      if (relu6) {
+        const float4 v = fma4(yv, sc, sh);
+        g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
+        g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
+        g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
+        g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
+      }
+      if (dz) st4(dz + off, g);
+      const float4 xh = make_float4((yv.x - mean.x) * istd.x, (yv.y - mean.y) * istd.y, (yv.z - mean.z) * istd.z,
+                                    (yv.w - mean.w) * istd.w);
+      s1 = s1 + g;
+      s2 = fma4(g, xh, s2);
+    }
+  }
+  __syncthreads();
+  if (pl < PPB) {
+    st4(red + ((size_t)pl * 2 + 0) * C + 4 * cg, s1);
+    st4(red + ((size_t)pl * 2 + 1) * C + 4 * cg, s2);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int p = 0; p < PPB; ++p) s += red[(size_t)p * 2 * C + i];
+    slab[(size_t)blockIdx.x * 2 * C + i] = s;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nrows, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ coef,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef3) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrows; ++r) {
+    s1 += (double)slab[(size_t)r * 2 * C + c];
+    s2 += (double)slab[(size_t)r * 2 * C + C + c];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  const double mean = coef[2 * C + c], istd = coef[3 * C + c];
+  const double s = (double)gamma[c] * istd;
+  const double k1 = s1 / count, k2 = s2 / count;
+  // dy = s*(dz - k1 - xhat*k2),  xhat = (y - mean)*istd
+  coef3[c] = (float)s;
+  coef3[C + c] = (float)(-s * k2 * istd);
+  coef3[2 * C + c] = (float)(-s * k1 + s * k2 * istd * mean);
+}
+
+}  // namespace
+
+NOISE_EXPORT int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, long count, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var,
+                                       long long* num_batches_tracked, float momentum, float eps, float* coef,
+                                       void* stream) {
+  NOISE_REQUIRE(slab && gamma && beta && coef && C > 0 && slab_rows > 0 && count > 0, "noise_bn_finalize_fwd: bad argument");
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, slab, slab_rows, C,
+                     (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, coef);
+  NOISE_CHECK_LAUNCH("noise_bn_finalize_fwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_bn_coef_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, float* coef, void* stream) {
+  NOISE_REQUIRE(gamma && beta && running_mean && running_var && coef && C > 0, "noise_bn_coef_eval: bad argument");
+  hipLaunchKernelGGL(bn_coef_eval_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, coef);
+  NOISE_CHECK_LAUNCH("noise_bn_coef_eval");
+  return 0;
+}
+
+// dz may alias g1 (in-place) or be null when there is neither a mask nor a second gradient.
+// scratch: noise_conv_max_blocks()*2*C floats.
+NOISE_EXPORT int noise_bn_bwd(const float* g1, const float* g2, const float* y, const float* coef, int relu6,
+                              const float* gamma, float* dz, float* dgamma, float* dbeta, float* coef3, float* scratch,
+                              long npix, int C, void* stream) {
+  NOISE_REQUIRE(g1 && y && coef && gamma && dgamma && dbeta && coef3 && scratch, "noise_bn_bwd: null pointer");
+  NOISE_REQUIRE(C >= 4 && C % 4 == 0 && npix > 0, "noise_bn_bwd: bad shape");
+  const int PPB = 256 / (C / 4);
+  const int grid = noise_grid(npix, PPB * 4, 1024);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float), st, g1, g2, y, coef,
+                     relu6, C, npix, dz, scratch);
+  NOISE_CHECK_LAUNCH("noise_bn_bwd/reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, st, scratch, grid, C, (double)npix, gamma,
+                     coef, dgamma, dbeta, coef3);
+  NOISE_CHECK_LAUNCH("noise_bn_bwd/finalize");
+  return 0;
+}

@@ -1,0 +1,512 @@
+// 3x3 stencil layers of the denoiser U-Net (NHWC fp32), gfx950.
+//
+// Replaces, per reference layer (train/models.py):
+//   * depthwise Conv2d k3 p1 s{1,2}  + BN + ReLU6            :385-393 (InvertedResidual "dw")
+//   * depthwise ConvTranspose2d k3 p1 s{1,2} + BN + ReLU6    :299-345 used at :1193-1201
+//   * first Conv2d 1->C0 k3 s2 p1                            :1151-1159 (with :589 pad, :614-622 normalise)
+//   * last ConvTranspose2d C0->1 k3 s2 p1 with bias          :1164-1171 (with :610 crop, :762-763 mask)
+// Every kernel writes the RAW convolution output; BatchNorm(+ReLU6) of the producer is applied by
+// the consumer's loader (LazySrc), and the per-channel sum / sum-of-squares needed for train-mode
+// batch statistics come out of the same pass as per-workgroup partials (no atomics).
+#include "lazy.h"
+
+namespace {
+
+struct ConvDims {
+  int B, Hi, Wi, Ho, Wo, C, sy, sx;
+};
+
+// Reduce per-thread float4 partials over the pixel lanes of a workgroup and write one row of the
+// slab: slab[block][j*C + c] for j < NV.  Threads are laid out tid = pl*CG + cg.
+template <int NV>
+__device__ __forceinline__ void block_channel_reduce(const float4 (&v)[NV], int C, int CG, int PPB, float* red,
+                                                     float* slab_row) {
+  const int tid = threadIdx.x;
+  const int pl = tid / CG, cg = tid - pl * CG;
+  __syncthreads();
+  if (pl < PPB) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) st4(red + ((size_t)pl * NV + j) * C + 4 * cg, v[j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < NV * C; i += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < PPB; ++p) s += red[(size_t)p * NV * C + i];
+    slab_row[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise forward: out[o][c] = sum_k in[src(o,k)][c] * w[c][k]
+template <int GEOM>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                     float* __restrict__ out, float* __restrict__ slab, ConvDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
+  const bool active = pl < PPB;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (active) {
+    const int c = 4 * cg;
+    const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
+    const long npix = (long)d.B * d.Ho * d.Wo;
+    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
+      const int ox = (int)(pix % d.Wo);
+      const long r = pix / d.Wo;
+      const int oy = (int)(r % d.Ho), bi = (int)(r / d.Ho);
+      float4 acc = f4(0.f);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = tap_src<GEOM>(oy, ky, d.sy, d.Hi);
+        if (iy < 0) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = tap_src<GEOM>(ox, kx, d.sx, d.Wi);
+          if (ix < 0) continue;
+          const size_t off = (((size_t)bi * d.Hi + iy) * d.Wi + ix) * C + c;
+          float4 v = lazy4_at(a, off);
+          if (b.present) v = v + lazy4_at(b, off);
+          acc = fma4(v, wk[ky * 3 + kx], acc);
+        }
+      }
+      st4(out + (size_t)pix * C + c, acc);
+      s1 = s1 + acc;
+      s2 = fma4(acc, acc, s2);
+    }
+  }
+  if (slab != nullptr) {
+    const float4 v[2] = {s1, s2};
+    block_channel_reduce<2>(v, C, CG, PPB, red, slab + (size_t)blockIdx.x * 2 * C);
+  }
+}
+
+// depthwise backward: for every INPUT pixel i gather the output gradients that touched it.
+//   g_in[i][c]  = sum_k dy[src(i,k)][c] * w[c][k]        (GEOM = adjoint geometry of the forward)
+//   dW[c][k]   += dy[src(i,k)][c] * a[i][c]
+template <int GEOM>
+__global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                     float* __restrict__ g_in, float* __restrict__ dw_slab,
+                                                     ConvDims d) {
+  // d.Hi/Wi: the layer's INPUT size (destination of this gather); d.Ho/Wo: its output size (source of dy)
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
+  const bool active = pl < PPB;
+  float4 dwk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dwk[k] = f4(0.f);
+  if (active) {
+    const int c = 4 * cg;
+    const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+    const LazyGrad4 g = lazygrad4_init(G, C, c);
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
+    const long npix = (long)d.B * d.Hi * d.Wi;
+    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
+      const int ix = (int)(pix % d.Wi);
+      const long r = pix / d.Wi;
+      const int iy = (int)(r % d.Hi), bi = (int)(r / d.Hi);
+      const size_t ioff = (size_t)pix * C + c;
+      float4 av = lazy4_at(a, ioff);
+      if (b.present) av = av + lazy4_at(b, ioff);
+      float4 acc = f4(0.f);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = tap_src<GEOM>(iy, ky, d.sy, d.Ho);
+        if (oy < 0) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = tap_src<GEOM>(ix, kx, d.sx, d.Wo);
+          if (ox < 0) continue;
+          const size_t off = (((size_t)bi * d.Ho + oy) * d.Wo + ox) * C + c;
+          const float4 dy = lazygrad4_at(g, off);
+          acc = fma4(dy, wk[ky * 3 + kx], acc);
+          dwk[ky * 3 + kx] = fma4(dy, av, dwk[ky * 3 + kx]);
+        }
+      }
+      if (g_in != nullptr) st4(g_in + ioff, acc);
+    }
+  }
+  // slab row layout: [k][C]  (the finalize kernel transposes to the (C,1,3,3) parameter layout)
+  block_channel_reduce<9>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 9 * C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// first layer: single-channel input, normalised by its per-clip max and padded on the fly.
+//   x_in(b, py, px) = pad_value if py < hp or px < wp else logmag[b][py-hp][px-wp] / (absmax[b] + 1e-6)
+struct FirstDims {
+  int B, H, W, hp, wp, Ho, Wo, C, sy, sx;
+  float pad_value;
+};
+
+__device__ __forceinline__ float first_input(const float* __restrict__ x, float mx, const FirstDims& d, int bi,
+                                             int py, int px) {
+  if (py < 0 || px < 0 || py >= d.H + d.hp || px >= d.W + d.wp) return 0.f;  // the conv's own zero padding
+  if (py < d.hp || px < d.wp) return d.pad_value;
+  return x[((size_t)bi * d.H + (py - d.hp)) * d.W + (px - d.wp)] / mx;
+}
+
+__global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ absmax,
+                                                             const float* __restrict__ w, float* __restrict__ out,
+                                                             float* __restrict__ slab, FirstDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
+  const bool active = pl < PPB;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (active) {
+    const int c = 4 * cg;
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
+    const long npix = (long)d.B * d.Ho * d.Wo;
+    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
+      const int ox = (int)(pix % d.Wo);
+      const long r = pix / d.Wo;
+      const int oy = (int)(r % d.Ho), bi = (int)(r / d.Ho);
+      const float mx = absmax[bi] + 1e-6f;
+      float4 acc = f4(0.f);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float v = first_input(x, mx, d, bi, oy * d.sy - 1 + ky, ox * d.sx - 1 + kx);
+          acc = fma4(f4(v), wk[ky * 3 + kx], acc);
+        }
+      st4(out + (size_t)pix * C + c, acc);
+      s1 = s1 + acc;
+      s2 = fma4(acc, acc, s2);
+    }
+  }
+  if (slab != nullptr) {
+    const float4 v[2] = {s1, s2};
+    block_channel_reduce<2>(v, C, CG, PPB, red, slab + (size_t)blockIdx.x * 2 * C);
+  }
+}
+
+// dW[c][k] = sum_o dy[o][c] * x_in(o*s - 1 + k)   (the input is data: no input gradient)
+__global__ __launch_bounds__(256) void first_conv_wgrad_kernel(LazyGrad G, const float* __restrict__ x,
+                                                               const float* __restrict__ absmax,
+                                                               float* __restrict__ dw_slab, FirstDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
+  float4 dwk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dwk[k] = f4(0.f);
+  if (pl < PPB) {
+    const int c = 4 * cg;
+    const LazyGrad4 g = lazygrad4_init(G, C, c);
+    const long npix = (long)d.B * d.Ho * d.Wo;
+    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
+      const int ox = (int)(pix % d.Wo);
+      const long r = pix / d.Wo;
+      const int oy = (int)(r % d.Ho), bi = (int)(r / d.Ho);
+      const float mx = absmax[bi] + 1e-6f;
+      const float4 dy = lazygrad4_at(g, (size_t)pix * C + c);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float v = first_input(x, mx, d, bi, oy * d.sy - 1 + ky, ox * d.sx - 1 + kx);
+          dwk[ky * 3 + kx] = fma4(dy, f4(v), dwk[ky * 3 + kx]);
+        }
+    }
+  }
+  block_channel_reduce<9>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 9 * C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// last layer: dense transposed conv C->1 with bias, cropped to the last H x W outputs, fused with
+// the additive mask:  enh = clamp(x/max + filt, -1, 1) * max        (train/models.py:762-763)
+struct LastDims {
+  int B, Hi, Wi, C, sy, sx;  // input (B,Hi,Wi,C)
+  int H, W, oy0, ox0;        // output crop: H x W starting at (oy0, ox0) of the full transposed-conv output
+};
+
+__global__ __launch_bounds__(256) void last_convT_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ logmag,
+                                                             const float* __restrict__ absmax, float* __restrict__ enh,
+                                                             float* __restrict__ filt_out, LastDims d) {
+  extern __shared__ float wl[];  // [9][C] + scaleA/shiftA/scaleB/shiftB [4][C]
+  const int C = d.C;
+  for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) wl[i] = w[(i % C) * 9 + i / C];
+  float* cf = wl + 9 * C;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    cf[i] = A.coef ? A.coef[i] : 1.f;
+    cf[C + i] = A.coef ? A.coef[C + i] : 0.f;
+    cf[2 * C + i] = (Bsrc.y && Bsrc.coef) ? Bsrc.coef[i] : 1.f;
+    cf[3 * C + i] = (Bsrc.y && Bsrc.coef) ? Bsrc.coef[C + i] : 0.f;
+  }
+  __syncthreads();
+  const long npix = (long)d.B * d.H * d.W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(pix % d.W);
+    const long r = pix / d.W;
+    const int oy = (int)(r % d.H), bi = (int)(r / d.H);
+    float acc = bias[0];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = tap_src<GEOM_CONVT>(oy + d.oy0, ky, d.sy, d.Hi);
+      if (iy < 0) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = tap_src<GEOM_CONVT>(ox + d.ox0, kx, d.sx, d.Wi);
+        if (ix < 0) continue;
+        const size_t off = (((size_t)bi * d.Hi + iy) * d.Wi + ix) * C;
+        const float* wk = wl + (ky * 3 + kx) * C;
+        for (int c = 0; c < C; c += 4) {
+          float4 v = fma4(ld4(A.y + off + c), ld4(cf + c), ld4(cf + C + c));
+          if (A.relu6) v = relu6_4(v);
+          if (Bsrc.y) {
+            float4 u = fma4(ld4(Bsrc.y + off + c), ld4(cf + 2 * C + c), ld4(cf + 3 * C + c));
+            if (Bsrc.relu6) u = relu6_4(u);
+            v = v + u;
+          }
+          const float4 ww = ld4(wk + c);
+          acc = fmaf(v.x, ww.x, acc);
+          acc = fmaf(v.y, ww.y, acc);
+          acc = fmaf(v.z, ww.z, acc);
+          acc = fmaf(v.w, ww.w, acc);
+        }
+      }
+    }
+    if (filt_out) filt_out[pix] = acc;
+    if (enh) {
+      const float mx = absmax[bi] + 1e-6f;
+      const float v = logmag[pix] / mx + acc;
+      enh[pix] = fminf(fmaxf(v, -1.f), 1.f) * mx;
+    }
+  }
+}
+
+// Backward of the last layer.  dy0[o] = d_enh[o] * max * [ |enh[o]| < max ]  on the cropped region.
+//   g_in[i][c] = sum_k dy0[i*s - 1 + k] * w[c][k];   dW[c][k] += a[i][c] * dy0[i*s - 1 + k];   db = sum dy0
+__global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __restrict__ d_enh, const float* __restrict__ enh,
+                                                             const float* __restrict__ absmax, LazySrc A, LazySrc Bsrc,
+                                                             const float* __restrict__ w, float* __restrict__ g_in,
+                                                             float* __restrict__ dw_slab, LastDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
+  float4 dwk[10];  // 9 taps + (channel group 0 only) the bias gradient in .x of slot 9
+#pragma unroll
+  for (int k = 0; k < 10; ++k) dwk[k] = f4(0.f);
+  if (pl < PPB) {
+    const int c = 4 * cg;
+    const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+    float4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
+    const long npix = (long)d.B * d.Hi * d.Wi;
+    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
+      const int ix = (int)(pix % d.Wi);
+      const long r = pix / d.Wi;
+      const int iy = (int)(r % d.Hi), bi = (int)(r / d.Hi);
+      const float mx = absmax[bi] + 1e-6f;
+      const size_t ioff = (size_t)pix * C + c;
+      float4 av = lazy4_at(a, ioff);
+      if (b.present) av = av + lazy4_at(b, ioff);
+      float4 acc = f4(0.f);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = iy * d.sy - 1 + ky - d.oy0;
+        if (oy < 0 || oy >= d.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = ix * d.sx - 1 + kx - d.ox0;
+          if (ox < 0 || ox >= d.W) continue;
+          const size_t o = ((size_t)bi * d.H + oy) * d.W + ox;
+          const float e = enh[o];
+          const float dy = (e > -mx && e < mx) ? d_enh[o] * mx : 0.f;
+          acc = fma4(f4(dy), wk[ky * 3 + kx], acc);
+          dwk[ky * 3 + kx] = fma4(f4(dy), av, dwk[ky * 3 + kx]);
+        }
+      }
+      st4(g_in + ioff, acc);
+    }
+    // bias gradient: every output position is owned by exactly one (pixel lane, cg==0) visit below
+    if (cg == 0) {
+      const long nout = (long)d.B * d.H * d.W;
+      float s = 0.f;
+      for (long o = (long)blockIdx.x * PPB + pl; o < nout; o += (long)gridDim.x * PPB) {
+        const int bi = (int)(o / ((long)d.H * d.W));
+        const float mx = absmax[bi] + 1e-6f;
+        const float e = enh[o];
+        s += (e > -mx && e < mx) ? d_enh[o] * mx : 0.f;
+      }
+      dwk[9].x = s;
+    }
+  }
+  block_channel_reduce<10>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 10 * C);
+}
+
+// out[j] = sum_b slab[b][j]; optional transpose from [k][C] slab rows to the (C,k) parameter layout
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols, int row_stride,
+                                   float* __restrict__ out, int tr_k, int tr_C, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncols) return;
+  double s = 0.0;
+  for (int b = 0; b < nrows; ++b) s += (double)slab[(size_t)b * row_stride + j];
+  int o = j;
+  if (tr_k > 0) {  // j = k*C + c  ->  c*tr_k + k
+    const int k = j / tr_C, c = j - k * tr_C;
+    if (k >= tr_k) return;
+    o = c * tr_k + k;
+  }
+  out[o] = accumulate ? out[o] + (float)s : (float)s;
+}
+
+int conv_grid(long npix, int C) {
+  const int PPB = 256 / (C / 4);
+  return noise_grid(npix, PPB * 4, 1024);
+}
+
+int check_c(const char* who, int C) {
+  NOISE_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, "%s: channel count %d must be a multiple of 4 in [4,1024]", who, C);
+  return 0;
+}
+
+}  // namespace
+
+NOISE_EXPORT int noise_conv_max_blocks(void) { return 1024; }
+
+// transposed = 0: Conv2d, 1: ConvTranspose2d (both k3, p1, groups=C, no bias)
+NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y,
+                                 const float* b_coef, int b_relu6, const float* w, float* out, float* stats_slab,
+                                 int* slab_rows, int transposed, int B, int Hi, int Wi, int C, int sy, int sx,
+                                 void* stream) {
+  if (check_c("noise_dw3x3_fwd", C)) return -1;
+  NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "noise_dw3x3_fwd: empty input");
+  NOISE_REQUIRE((sy == 1 || sy == 2) && (sx == 1 || sx == 2), "noise_dw3x3_fwd: stride must be 1 or 2");
+  NOISE_REQUIRE(a_y && w && out, "noise_dw3x3_fwd: null pointer");
+  ConvDims d;
+  d.B = B; d.Hi = Hi; d.Wi = Wi; d.C = C; d.sy = sy; d.sx = sx;
+  d.Ho = transposed ? (Hi - 1) * sy + 1 : (Hi - 1) / sy + 1;
+  d.Wo = transposed ? (Wi - 1) * sx + 1 : (Wi - 1) / sx + 1;
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
+  const int PPB = 256 / (C / 4);
+  const size_t smem = (size_t)PPB * 2 * C * sizeof(float);
+  if (slab_rows) *slab_rows = grid;
+  if (transposed)
+    hipLaunchKernelGGL(dw_fwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, (hipStream_t)stream, A, Bs, w, out, stats_slab, d);
+  else
+    hipLaunchKernelGGL(dw_fwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, (hipStream_t)stream, A, Bs, w, out, stats_slab, d);
+  NOISE_CHECK_LAUNCH("noise_dw3x3_fwd");
+  return 0;
+}
+
+// Backward of noise_dw3x3_fwd.  (Hi,Wi) is the forward INPUT size.  Writes g_in (B,Hi,Wi,C) and dw (C,3,3).
+// scratch: at least noise_conv_max_blocks()*9*C floats.
+NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y,
+                                 const float* a_coef, int a_relu6, const float* b_y, const float* b_coef, int b_relu6,
+                                 const float* w, float* g_in, float* dw, float* scratch, int transposed, int B, int Hi,
+                                 int Wi, int C, int sy, int sx, void* stream) {
+  if (check_c("noise_dw3x3_bwd", C)) return -1;
+  NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "noise_dw3x3_bwd: empty input");
+  NOISE_REQUIRE((sy == 1 || sy == 2) && (sx == 1 || sx == 2), "noise_dw3x3_bwd: stride must be 1 or 2");
+  NOISE_REQUIRE(dz && a_y && w && dw && scratch, "noise_dw3x3_bwd: null pointer");
+  NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_dw3x3_bwd: coef3 needs y_out");
+  ConvDims d;
+  d.B = B; d.Hi = Hi; d.Wi = Wi; d.C = C; d.sy = sy; d.sx = sx;
+  d.Ho = transposed ? (Hi - 1) * sy + 1 : (Hi - 1) / sy + 1;
+  d.Wo = transposed ? (Wi - 1) * sx + 1 : (Wi - 1) / sx + 1;
+  LazyGrad G{dz, y_out, coef3};
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  const int grid = conv_grid((long)B * Hi * Wi, C);
+  const int PPB = 256 / (C / 4);
+  const size_t smem = (size_t)PPB * 9 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  // the adjoint of a CONV gather is a CONVT gather and vice versa
+  if (transposed)
+    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, d);
+  else
+    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, d);
+  NOISE_CHECK_LAUNCH("noise_dw3x3_bwd");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 256)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
+  NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
+  return 0;
+}
+
+NOISE_EXPORT int noise_first_conv_fwd(const float* logmag, const float* absmax, const float* w, float* out,
+                                      float* stats_slab, int* slab_rows, int B, int H, int W, int hp, int wp,
+                                      float pad_value, int C, int sy, int sx, void* stream) {
+  if (check_c("noise_first_conv_fwd", C)) return -1;
+  NOISE_REQUIRE(B > 0 && H > 0 && W > 0 && hp >= 0 && wp >= 0, "noise_first_conv_fwd: bad shape");
+  NOISE_REQUIRE(logmag && absmax && w && out, "noise_first_conv_fwd: null pointer");
+  FirstDims d{B, H, W, hp, wp, (H + hp - 1) / sy + 1, (W + wp - 1) / sx + 1, C, sy, sx, pad_value};
+  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
+  const int PPB = 256 / (C / 4);
+  if (slab_rows) *slab_rows = grid;
+  hipLaunchKernelGGL(first_conv_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
+                     (hipStream_t)stream, logmag, absmax, w, out, stats_slab, d);
+  NOISE_CHECK_LAUNCH("noise_first_conv_fwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, const float* coef3, const float* logmag,
+                                        const float* absmax, float* dw, float* scratch, int B, int H, int W, int hp,
+                                        int wp, float pad_value, int C, int sy, int sx, void* stream) {
+  if (check_c("noise_first_conv_wgrad", C)) return -1;
+  NOISE_REQUIRE(dz && logmag && absmax && dw && scratch, "noise_first_conv_wgrad: null pointer");
+  FirstDims d{B, H, W, hp, wp, (H + hp - 1) / sy + 1, (W + wp - 1) / sx + 1, C, sy, sx, pad_value};
+  LazyGrad G{dz, y_out, coef3};
+  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
+  const int PPB = 256 / (C / 4);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
+                     absmax, scratch, d);
+  NOISE_CHECK_LAUNCH("noise_first_conv_wgrad");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 256)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
+  NOISE_CHECK_LAUNCH("noise_first_conv_wgrad/reduce");
+  return 0;
+}
+
+// enh (B,H,W) = clamp(logmag/max + filt, -1, 1) * max, filt = crop(convT(a) + bias).  Either output may be null.
+NOISE_EXPORT int noise_last_convT_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y,
+                                      const float* b_coef, int b_relu6, const float* w, const float* bias,
+                                      const float* logmag, const float* absmax, float* enh, float* filt, int B, int Hi,
+                                      int Wi, int C, int sy, int sx, int H, int W, void* stream) {
+  if (check_c("noise_last_convT_fwd", C)) return -1;
+  NOISE_REQUIRE(a_y && w && bias && (filt || (enh && logmag && absmax)), "noise_last_convT_fwd: null pointer");
+  const int Hfull = (Hi - 1) * sy + 1, Wfull = (Wi - 1) * sx + 1;
+  NOISE_REQUIRE(Hfull >= H && Wfull >= W, "noise_last_convT_fwd: output %dx%d smaller than requested crop %dx%d", Hfull, Wfull, H, W);
+  LastDims d{B, Hi, Wi, C, sy, sx, H, W, Hfull - H, Wfull - W};
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  const int grid = noise_grid((long)B * H * W, 256, 4096);
+  hipLaunchKernelGGL(last_convT_fwd_kernel, dim3(grid), dim3(256), (size_t)13 * C * sizeof(float), (hipStream_t)stream, A,
+                     Bs, w, bias, logmag, absmax, enh, filt, d);
+  NOISE_CHECK_LAUNCH("noise_last_convT_fwd");
+  return 0;
+}
+
+// g_in (B,Hi,Wi,C), dw (C,1,3,3), dbias (1).  scratch: noise_conv_max_blocks()*10*C floats.
+NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, const float* absmax, const float* a_y,
+                                      const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
+                                      int b_relu6, const float* w, float* g_in, float* dw, float* dbias, float* scratch,
+                                      int B, int Hi, int Wi, int C, int sy, int sx, int H, int W, void* stream) {
+  if (check_c("noise_last_convT_bwd", C)) return -1;
+  NOISE_REQUIRE(d_enh && enh && absmax && a_y && w && g_in && dw && dbias && scratch, "noise_last_convT_bwd: null pointer");
+  const int Hfull = (Hi - 1) * sy + 1, Wfull = (Wi - 1) * sx + 1;
+  NOISE_REQUIRE(Hfull >= H && Wfull >= W, "noise_last_convT_bwd: bad crop");
+  LastDims d{B, Hi, Wi, C, sy, sx, H, W, Hfull - H, Wfull - W};
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  const int grid = conv_grid((long)B * Hi * Wi, C);
+  const int PPB = 256 / (C / 4);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 10 * C * sizeof(float), st, d_enh, enh,
+                     absmax, A, Bs, w, g_in, scratch, d);
+  NOISE_CHECK_LAUNCH("noise_last_convT_bwd");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(10 * C, 256)), dim3(256), 0, st, scratch, grid, 10 * C, 10 * C, dw, 9, C, 0);
+  NOISE_CHECK_LAUNCH("noise_last_convT_bwd/reduce");
+  // the bias gradient sits at slab column 9*C (slot 9, channel 0)
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(64), 0, st, scratch + 9 * C, grid, 1, 10 * C, dbias, 0, 0, 0);
+  NOISE_CHECK_LAUNCH("noise_last_convT_bwd/bias");
+  return 0;
+}

@@ -1,0 +1,100 @@
+// Device-side loaders for lazily normalised tensors (see common.h: LazySrc / LazyGrad).
+// All activations are NHWC fp32; channel counts are multiples of 4 so a lane moves float4.
+#pragma once
+#include "common.h"
+
+#ifdef __HIPCC__
+enum { ACT_NONE = 0, ACT_RELU6 = 1 };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 relu6_4(float4 v) { return make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w)); }
+
+// Per-thread view of one lazy source restricted to 4 consecutive channels c..c+3.
+struct Lazy4 {
+  const float* y;
+  float4 scale, shift;
+  int act;
+  bool present;
+};
+
+__device__ __forceinline__ Lazy4 lazy4_init(const LazySrc& s, int C, int c) {
+  Lazy4 r;
+  r.y = s.y;
+  r.present = s.y != nullptr;
+  r.act = s.relu6;
+  r.scale = f4(1.f);
+  r.shift = f4(0.f);
+  if (r.present && s.coef != nullptr) {
+    r.scale = ld4(s.coef + c);
+    r.shift = ld4(s.coef + C + c);
+  }
+  return r;
+}
+
+// value of the source at flat element offset `off` (= pixel*C + c)
+__device__ __forceinline__ float4 lazy4_at(const Lazy4& s, size_t off) {
+  float4 v = fma4(ld4(s.y + off), s.scale, s.shift);
+  return s.act == ACT_RELU6 ? relu6_4(v) : v;
+}
+
+// Per-thread view of a lazy gradient restricted to 4 consecutive channels.
+struct LazyGrad4 {
+  const float* dz;
+  const float* y;
+  float4 s, alpha, beta;
+  bool affine;
+};
+
+__device__ __forceinline__ LazyGrad4 lazygrad4_init(const LazyGrad& g, int C, int c) {
+  LazyGrad4 r;
+  r.dz = g.dz;
+  r.y = g.y;
+  r.affine = g.coef3 != nullptr;
+  r.s = f4(1.f);
+  r.alpha = f4(0.f);
+  r.beta = f4(0.f);
+  if (r.affine) {
+    r.s = ld4(g.coef3 + c);
+    r.alpha = ld4(g.coef3 + C + c);
+    r.beta = ld4(g.coef3 + 2 * C + c);
+  }
+  return r;
+}
+
+__device__ __forceinline__ float4 lazygrad4_at(const LazyGrad4& g, size_t off) {
+  float4 d = ld4(g.dz + off);
+  if (!g.affine) return d;
+  return fma4(g.s, d, fma4(g.alpha, ld4(g.y + off), g.beta));
+}
+
+// Gather geometry of a 3x3, pad-1 stencil along one axis.
+//   GEOM_CONV : source index of tap k for destination o  ->  o*s - 1 + k
+//   GEOM_CONVT: source index of tap k for destination o  ->  (o + 1 - k)/s when divisible
+// Returns -1 when the tap falls outside [0, n_src) or does not exist.
+enum { GEOM_CONV = 0, GEOM_CONVT = 1 };
+
+template <int GEOM>
+__device__ __forceinline__ int tap_src(int o, int k, int s, int n_src) {
+  int i;
+  if (GEOM == GEOM_CONV) {
+    i = o * s - 1 + k;
+  } else {
+    const int t = o + 1 - k;
+    if (t < 0) return -1;
+    if (s == 2) {
+      if (t & 1) return -1;
+      i = t >> 1;
+    } else {
+      i = t;
+    }
+  }
+  return (i >= 0 && i < n_src) ? i : -1;
+}
+#endif

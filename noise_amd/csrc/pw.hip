@@ -1,0 +1,340 @@
+// Pointwise (1x1) convolutions of the inverted-residual blocks as fp32-MFMA tile products, gfx950.
+//
+// Replaces train/models.py:371-381 (expand 1x1 + BN + ReLU6) and :395-396 (linear 1x1 + BN) in
+// forward, and their input/weight gradients in backward.  Activations are NHWC fp32, so a layer is
+//     out[p][co] = sum_ci a[p][ci] * W[co][ci]           p = flattened (b,y,x)
+// with a[] the lazily normalised input (one or two sources: decoder inputs are x + skip).
+//
+// v_mfma_f32_16x16x4_f32 with A = weights (rows = co), B = activations (cols = 16 pixels): a lane then
+// owns 4 consecutive output channels of one pixel, i.e. one 16-byte NHWC store.  The k index of the
+// four MFMAs of a 16-channel chunk is permuted so that both operands are fetched as float4
+// (lane (p,q) holds channels 16j+4q..+3 and feeds element r to MFMA r).  Weights are staged once per
+// workgroup in LDS in exactly that fragment order (conflict-free ds_read_b128).
+#include "lazy.h"
+
+namespace {
+
+struct PwDims {
+  long npix;
+  int K, N, transW;  // N: output channels = output row stride (multiple of 4)
+};
+
+// GRAD = false: input = LazySrc A (+B);   GRAD = true: input = LazyGrad G (dy rebuilt on the fly)
+template <bool GRAD, int KC, int MT>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, LazyGrad G, const float* __restrict__ W,
+                                                      const float* __restrict__ add, float* __restrict__ out,
+                                                      float* __restrict__ slab, PwDims d) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int K = d.K, N = d.N;
+  float* wfrag = lds;                    // [MT][KC][64][4]
+  float* cf = lds + MT * KC * 256;       // [4][KC*16]
+  constexpr int KP = KC * 16;
+  for (int idx = tid; idx < MT * KC * 256; idx += 256) {
+    const int r = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+    const int jj = t % KC, m = t / KC;
+    const int co = 16 * m + (l & 15), ci = 16 * jj + 4 * (l >> 4) + r;
+    float v = 0.f;
+    if (co < N && ci < K) v = d.transW ? W[(size_t)ci * N + co] : W[(size_t)co * K + ci];
+    wfrag[idx] = v;
+  }
+  for (int k = tid; k < KP; k += 256) {
+    const bool in = k < K;
+    if (GRAD) {
+      cf[k] = (in && G.coef3) ? G.coef3[k] : 1.f;
+      cf[KP + k] = (in && G.coef3) ? G.coef3[K + k] : 0.f;
+      cf[2 * KP + k] = (in && G.coef3) ? G.coef3[2 * K + k] : 0.f;
+    } else {
+      cf[k] = (in && A.coef) ? A.coef[k] : 1.f;
+      cf[KP + k] = (in && A.coef) ? A.coef[K + k] : 0.f;
+      cf[2 * KP + k] = (in && Bs.y && Bs.coef) ? Bs.coef[k] : 1.f;
+      cf[3 * KP + k] = (in && Bs.y && Bs.coef) ? Bs.coef[K + k] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  float4 s1[MT], s2[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) s1[m] = s2[m] = f4(0.f);
+
+  const long ntiles = (d.npix + 15) >> 4;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long pix = tile * 16 + p;
+    const bool valid = pix < d.npix;
+    float4 in[KC];
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) {
+      const int ci = 16 * jj + 4 * q;
+      float4 v = f4(0.f);
+      if (valid && ci < K) {
+        const size_t off = (size_t)pix * K + ci;
+        if (GRAD) {
+          v = ld4(G.dz + off);
+          if (G.coef3) v = fma4(ld4(cf + ci), v, fma4(ld4(cf + KP + ci), ld4(G.y + off), ld4(cf + 2 * KP + ci)));
+        } else {
+          v = fma4(ld4(A.y + off), ld4(cf + ci), ld4(cf + KP + ci));
+          if (A.relu6) v = relu6_4(v);
+          if (Bs.y) {
+            float4 u = fma4(ld4(Bs.y + off), ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci));
+            if (Bs.relu6) u = relu6_4(u);
+            v = v + u;
+          }
+        }
+      }
+      in[jj] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < KC; ++jj) {
+        const float4 wa = ld4(wfrag + ((m * KC + jj) * 64 + lane) * 4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, acc, 0, 0, 0);
+      }
+      const int co = 16 * m + 4 * q;
+      float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (valid && co < N) {
+        const size_t ooff = (size_t)pix * N + co;
+        if (add) o = o + ld4(add + ooff);
+        st4(out + ooff, o);
+        s1[m] = s1[m] + o;
+        s2[m] = fma4(o, o, s2[m]);
+      }
+    }
+  }
+
+  if (slab != nullptr) {
+    // reduce over the 16 pixel lanes that share q, then over the 4 waves through LDS
+    __syncthreads();
+    float* red = lds;  // reuse: [4 waves][2][MT*16]
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v[8] = {s1[m].x, s1[m].y, s1[m].z, s1[m].w, s2[m].x, s2[m].y, s2[m].z, s2[m].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v[e] += __shfl_xor(v[e], o, 64);
+      }
+      if (p == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[(wave * 2 + 0) * MT * 16 + 16 * m + 4 * q + e] = v[e];
+          red[(wave * 2 + 1) * MT * 16 + 16 * m + 4 * q + e] = v[4 + e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * N; i += 256) {
+      const int j = i / N, c = i - j * N;
+      float s = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) s += red[(wv * 2 + j) * MT * 16 + c];
+      slab[(size_t)blockIdx.x * 2 * N + i] = s;
+    }
+  }
+}
+
+// dW[co][ci] = sum_p dy[p][co] * a[p][ci]:   A[i=co][k=pixel], B[k=pixel][j=ci]; 4 pixels per MFMA.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, LazySrc Bs, float* __restrict__ slab,
+                                                       long npix, int N, int K) {
+  extern __shared__ float lds[];  // [N][K] cross-wave reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  float gs[MT], ga[MT], gb[MT];
+  float as[NT], at[NT], bs[NT], bt[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co = 16 * m + i;
+    const bool in = co < N && G.coef3;
+    gs[m] = in ? G.coef3[co] : 1.f;
+    ga[m] = in ? G.coef3[N + co] : 0.f;
+    gb[m] = in ? G.coef3[2 * N + co] : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int ci = 16 * n + i;
+    const bool ina = ci < K && A.coef, inb = ci < K && Bs.y && Bs.coef;
+    as[n] = ina ? A.coef[ci] : 1.f;
+    at[n] = ina ? A.coef[K + ci] : 0.f;
+    bs[n] = inb ? Bs.coef[ci] : 1.f;
+    bt[n] = inb ? Bs.coef[K + ci] : 0.f;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long ngroups = (npix + 3) >> 2;
+  for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
+    const long pix = g * 4 + kq;
+    const bool valid = pix < npix;
+    float dy[MT], av[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co = 16 * m + i;
+      float v = 0.f;
+      if (valid && co < N) {
+        const size_t off = (size_t)pix * N + co;
+        v = G.dz[off];
+        if (G.coef3) v = fmaf(gs[m], v, fmaf(ga[m], G.y[off], gb[m]));
+      }
+      dy[m] = v;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int ci = 16 * n + i;
+      float v = 0.f;
+      if (valid && ci < K) {
+        const size_t off = (size_t)pix * K + ci;
+        v = fmaf(A.y[off], as[n], at[n]);
+        if (A.relu6) v = relu6f(v);
+        if (Bs.y) {
+          float u = fmaf(Bs.y[off], bs[n], bt[n]);
+          if (Bs.relu6) u = relu6f(u);
+          v += u;
+        }
+      }
+      av[n] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[m], av[n], acc[m][n], 0, 0, 0);
+  }
+
+  // D layout: col = ci0 + (lane&15), rows = co0 + 4*(lane>>4) + reg.  Fold the four waves through LDS.
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int ci = 16 * n + i;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = 16 * m + 4 * kq + e;
+            if (co < N && ci < K) {
+              float* dst = lds + co * K + ci;
+              *dst = (wv == 0) ? acc[m][n][e] : *dst + acc[m][n][e];
+            }
+          }
+        }
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < N * K; j += 256) slab[(size_t)blockIdx.x * N * K + j] = lds[j];
+}
+
+__global__ void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols, float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncols) return;
+  double s = 0.0;
+  for (int b = 0; b < nrows; ++b) s += (double)slab[(size_t)b * ncols + j];
+  out[j] = (float)s;
+}
+
+template <bool GRAD, int KC, int MT>
+void launch_pw(LazySrc A, LazySrc Bs, LazyGrad G, const float* W, const float* add, float* out, float* slab, PwDims d,
+               int grid, hipStream_t st) {
+  size_t smem = (size_t)(MT * KC * 256 + 4 * KC * 16) * sizeof(float);
+  const size_t red = (size_t)8 * MT * 16 * sizeof(float);
+  if (red > smem) smem = red;
+  hipLaunchKernelGGL((pw_gemm_kernel<GRAD, KC, MT>), dim3(grid), dim3(256), smem, st, A, Bs, G, W, add, out, slab, d);
+}
+
+#define PW_CASES(X)                                                                                     \
+  X(1, 1) X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(2, 1) X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 12)  \
+  X(3, 1) X(3, 2) X(3, 3) X(3, 4) X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(4, 6) X(4, 12) X(5, 1) X(5, 2) X(5, 5) \
+  X(6, 1) X(6, 2) X(6, 4) X(6, 6) X(12, 2) X(12, 4) X(12, 12)
+
+template <bool GRAD>
+int dispatch_pw(int KC, int MT, LazySrc A, LazySrc Bs, LazyGrad G, const float* W, const float* add, float* out,
+                float* slab, PwDims d, int grid, hipStream_t st) {
+#define X(kc, mt)                                                          \
+  if (KC == kc && MT == mt) {                                              \
+    launch_pw<GRAD, kc, mt>(A, Bs, G, W, add, out, slab, d, grid, st);     \
+    return 0;                                                              \
+  }
+  PW_CASES(X)
+#undef X
+  return 1;
+}
+
+int pw_grid(long npix) { return noise_grid(npix, 16 * 4 * 4, 1024); }
+
+}  // namespace
+
+// out (npix, N) raw = a (npix, K) x W^T, W (N, K).
+// stats_slab (optional): per-workgroup [sum(N) | sumsq(N)] rows; *slab_rows receives the row count.
+NOISE_EXPORT int noise_pw_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
+                              int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, long npix,
+                              int K, int N, void* stream) {
+  NOISE_REQUIRE(a_y && w && out && npix > 0, "noise_pw_fwd: bad argument");
+  NOISE_REQUIRE(K >= 8 && K % 8 == 0 && N >= 4 && N % 4 == 0, "noise_pw_fwd: K=%d must be a multiple of 8, N=%d of 4", K, N);
+  const int KC = (K + 15) / 16, MT = (N + 15) / 16;
+  PwDims d{npix, K, N, 0};
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  LazyGrad G{nullptr, nullptr, nullptr};
+  const int grid = pw_grid(npix);
+  if (slab_rows) *slab_rows = grid;
+  NOISE_REQUIRE(dispatch_pw<false>(KC, MT, A, Bs, G, w, nullptr, out, stats_slab, d, grid, (hipStream_t)stream) == 0,
+                "noise_pw_fwd: no kernel instance for K=%d N=%d", K, N);
+  NOISE_CHECK_LAUNCH("noise_pw_fwd");
+  return 0;
+}
+
+// g_in (npix, Cin) = dy (npix, Cout) x W, W (Cout, Cin); dy = s*dz + alpha*y + beta (coef3 may be null).
+// `add` (optional, same shape as g_in) is summed into the result: the second gradient of a skip tensor.
+NOISE_EXPORT int noise_pw_dgrad(const float* dz, const float* y_out, const float* coef3, const float* w, const float* add,
+                                float* g_in, long npix, int Cout, int Cin, void* stream) {
+  NOISE_REQUIRE(dz && w && g_in && npix > 0, "noise_pw_dgrad: bad argument");
+  NOISE_REQUIRE(Cout % 8 == 0 && Cin % 4 == 0, "noise_pw_dgrad: Cout=%d must be a multiple of 8 and Cin=%d of 4", Cout, Cin);
+  NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_pw_dgrad: coef3 needs y_out");
+  const int KC = (Cout + 15) / 16, MT = (Cin + 15) / 16;
+  PwDims d{npix, Cout, Cin, 1};
+  LazySrc A{nullptr, nullptr, 0};
+  LazyGrad G{dz, y_out, coef3};
+  NOISE_REQUIRE(dispatch_pw<true>(KC, MT, A, A, G, w, add, g_in, nullptr, d, pw_grid(npix), (hipStream_t)stream) == 0,
+                "noise_pw_dgrad: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
+  NOISE_CHECK_LAUNCH("noise_pw_dgrad");
+  return 0;
+}
+
+NOISE_EXPORT int noise_pw_wgrad_max_blocks(void) { return 256; }
+
+// dw (Cout, Cin).  scratch: noise_pw_wgrad_max_blocks()*Cout*Cin floats.
+NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float* coef3, const float* a_y,
+                                const float* a_coef, int a_relu6, const float* b_y, const float* b_coef, int b_relu6,
+                                float* dw, float* scratch, long npix, int Cout, int Cin, void* stream) {
+  NOISE_REQUIRE(dz && a_y && dw && scratch && npix > 0, "noise_pw_wgrad: bad argument");
+  NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_pw_wgrad: coef3 needs y_out");
+  NOISE_REQUIRE((size_t)Cout * Cin * 4 <= 64 * 1024, "noise_pw_wgrad: %dx%d weight too large for the LDS fold", Cout, Cin);
+  const int MT = (Cout + 15) / 16, NT = (Cin + 15) / 16;
+  LazyGrad G{dz, y_out, coef3};
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  const int grid = noise_grid(npix, 256, 256);
+  const size_t smem = (size_t)Cout * Cin * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  bool done = false;
+#define X(nt, mt)                                                                                                      \
+  if constexpr (mt * nt <= 48) {                                                                                       \
+    if (!done && MT == mt && NT == nt) {                                                                               \
+      hipLaunchKernelGGL((pw_wgrad_kernel<mt, nt>), dim3(grid), dim3(256), smem, st, G, A, Bs, scratch, npix, Cout, Cin); \
+      done = true;                                                                                                     \
+    }                                                                                                                  \
+  }
+  PW_CASES(X)
+#undef X
+  NOISE_REQUIRE(done, "noise_pw_wgrad: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
+  NOISE_CHECK_LAUNCH("noise_pw_wgrad");
+  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 256)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
+  NOISE_CHECK_LAUNCH("noise_pw_wgrad/reduce");
+  return 0;
+}

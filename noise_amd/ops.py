@@ -1,0 +1,115 @@
+"""Thin Python wrappers over the C-ABI entry points of the denoiser kernels.
+
+Tensors are NHWC fp32 CUDA tensors.  A "lazy source" is a tuple (y, coef, relu6): the raw conv
+output, the [scale|shift|mean|invstd] coefficient vector of the BatchNorm that follows it (or None)
+and whether a ReLU6 follows.  A "lazy gradient" is (dz, y, coef3) with coef3 = [s|alpha|beta] or None.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+_lib.register({
+    "noise_dw3x3_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_dw3x3_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_first_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "noise_first_conv_wgrad": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "noise_last_convT_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_last_convT_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_bn_finalize_fwd": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P, _P],
+    "noise_bn_coef_eval": [_I, _P, _P, _P, _P, _F, _P, _P],
+    "noise_bn_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "noise_pw_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
+    "noise_pw_dgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "noise_pw_wgrad": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _I, _I, _P],
+})
+_lib.lib.noise_conv_max_blocks.restype = ctypes.c_int
+_lib.lib.noise_pw_wgrad_max_blocks.restype = ctypes.c_int
+CONV_MAX_BLOCKS = _lib.lib.noise_conv_max_blocks()
+PW_WGRAD_MAX_BLOCKS = _lib.lib.noise_pw_wgrad_max_blocks()
+
+NONE = (None, None, 0)
+
+
+def _src(s):
+    y, coef, relu6 = s if s is not None else NONE
+    return ptr(y), ptr(coef), int(bool(relu6))
+
+
+def conv_out(n, s, transposed):
+    return (n - 1) * s + 1 if transposed else (n - 1) // s + 1
+
+
+def dw3x3_fwd(a, b, w, out, slab, transposed, B, Hi, Wi, C, stride):
+    """Returns the number of slab rows written (0 when slab is None)."""
+    rows = ctypes.c_int(0)
+    _lib.call("noise_dw3x3_fwd", *_src(a), *_src(b), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows),
+              int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream())
+    return rows.value
+
+
+def dw3x3_bwd(grad, a, b, w, g_in, dw, scratch, transposed, B, Hi, Wi, C, stride):
+    dz, y, coef3 = grad
+    _lib.call("noise_dw3x3_bwd", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(w), ptr(g_in), ptr(dw),
+              ptr(scratch), int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream())
+
+
+def first_conv_fwd(logmag, absmax, w, out, slab, B, H, W, hp, wp, pad_value, C, stride):
+    rows = ctypes.c_int(0)
+    _lib.call("noise_first_conv_fwd", ptr(logmag), ptr(absmax), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows),
+              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream())
+    return rows.value
+
+
+def first_conv_wgrad(grad, logmag, absmax, dw, scratch, B, H, W, hp, wp, pad_value, C, stride):
+    dz, y, coef3 = grad
+    _lib.call("noise_first_conv_wgrad", ptr(dz), ptr(y), ptr(coef3), ptr(logmag), ptr(absmax), ptr(dw), ptr(scratch),
+              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream())
+
+
+def last_convT_fwd(a, b, w, bias, logmag, absmax, enh, filt, B, Hi, Wi, C, stride, H, W):
+    _lib.call("noise_last_convT_fwd", *_src(a), *_src(b), ptr(w), ptr(bias), ptr(logmag), ptr(absmax), ptr(enh),
+              ptr(filt), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream())
+
+
+def last_convT_bwd(d_enh, enh, absmax, a, b, w, g_in, dw, dbias, scratch, B, Hi, Wi, C, stride, H, W):
+    _lib.call("noise_last_convT_bwd", ptr(d_enh), ptr(enh), ptr(absmax), *_src(a), *_src(b), ptr(w), ptr(g_in),
+              ptr(dw), ptr(dbias), ptr(scratch), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream())
+
+
+def bn_finalize_fwd(slab, rows, C, count, gamma, beta, running_mean, running_var, nbt, coef, momentum=0.1, eps=1e-5):
+    _lib.call("noise_bn_finalize_fwd", ptr(slab), rows, C, count, ptr(gamma), ptr(beta), ptr(running_mean),
+              ptr(running_var), ptr(nbt), float(momentum), float(eps), ptr(coef), _lib.stream())
+
+
+def bn_coef_eval(C, gamma, beta, running_mean, running_var, coef, eps=1e-5):
+    _lib.call("noise_bn_coef_eval", C, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
+              ptr(coef), _lib.stream())
+
+
+def bn_bwd(g1, g2, y, coef, relu6, gamma, dz, dgamma, dbeta, coef3, scratch, npix, C):
+    _lib.call("noise_bn_bwd", ptr(g1), ptr(g2), ptr(y), ptr(coef), int(bool(relu6)), ptr(gamma), ptr(dz), ptr(dgamma),
+              ptr(dbeta), ptr(coef3), ptr(scratch), npix, C, _lib.stream())
+
+
+def pw_fwd(a, b, w, out, slab, npix, K, N):
+    rows = ctypes.c_int(0)
+    _lib.call("noise_pw_fwd", *_src(a), *_src(b), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows), npix, K, N,
+              _lib.stream())
+    return rows.value
+
+
+def pw_dgrad(grad, w, add, g_in, npix, Cout, Cin):
+    dz, y, coef3 = grad
+    _lib.call("noise_pw_dgrad", ptr(dz), ptr(y), ptr(coef3), ptr(w), ptr(add), ptr(g_in), npix, Cout, Cin,
+              _lib.stream())
+
+
+def pw_wgrad(grad, a, b, dw, scratch, npix, Cout, Cin):
+    dz, y, coef3 = grad
+    _lib.call("noise_pw_wgrad", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(dw), ptr(scratch), npix, Cout,
+              Cin, _lib.stream())

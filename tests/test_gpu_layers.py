@@ -1,0 +1,266 @@
+"""GPU parity of the individual denoiser kernels against plain PyTorch fp32 ops on the CPU
+(forward values, batch statistics, input gradients and weight gradients)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rand_coef(C, g):
+    """[scale | shift | mean | invstd] of a made-up BatchNorm."""
+    gamma = 1 + 0.3 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    mean = 0.3 * torch.randn(C, generator=g)
+    invstd = 0.5 + torch.rand(C, generator=g)
+    scale = gamma * invstd
+    return torch.cat([scale, beta - mean * scale, mean, invstd])
+
+
+def lazy_ref(y, coef, relu6):
+    C = y.shape[1]
+    v = y * coef[:C].view(1, C, 1, 1) + coef[C:2 * C].view(1, C, 1, 1)
+    return F.relu6(v) if relu6 else v
+
+
+def close(a, b, tol=2e-5, msg=""):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    scale = max(np.abs(b).max(), 1e-6)
+    err = np.abs(a - b).max() / scale
+    assert err < tol, f"{msg}: rel err {err:.3e}"
+
+
+def slab_stats(slab, rows, C):
+    s = slab[: rows * 2 * C].view(rows, 2, C).double().sum(0).cpu()
+    return s[0], s[1]
+
+
+@pytest.mark.parametrize("C,stride,transposed,two_src,shape", [
+    (32, (1, 1), False, False, (3, 9, 7)),
+    (48, (2, 2), False, False, (2, 81, 33)),
+    (72, (2, 2), False, False, (2, 10, 12)),
+    (96, (2, 1), False, False, (2, 8, 5)),
+    (192, (2, 2), True, False, (2, 11, 5)),
+    (96, (2, 2), True, False, (2, 6, 4)),
+    (72, (2, 2), True, False, (1, 41, 17)),
+    (16, (1, 1), True, True, (2, 9, 6)),
+])
+def test_depthwise(dev, C, stride, transposed, two_src, shape):
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(C + stride[0])
+    B, Hi, Wi = shape
+    ya = torch.randn(B, C, Hi, Wi, generator=g)
+    ca = rand_coef(C, g)
+    yb = torch.randn(B, C, Hi, Wi, generator=g) if two_src else None
+    cb = rand_coef(C, g) if two_src else None
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.4).requires_grad_(True)
+    ya_r = ya.clone().requires_grad_(True)
+    a_in = lazy_ref(ya_r, ca, not two_src)
+    if two_src:
+        a_in = a_in + lazy_ref(yb, cb, False)
+    a_in.retain_grad()
+    if transposed:
+        ref = F.conv_transpose2d(a_in, w, stride=stride, padding=1, groups=C)
+    else:
+        ref = F.conv2d(a_in, w, stride=stride, padding=1, groups=C)
+    Ho, Wo = ref.shape[-2:]
+    assert Ho == ops.conv_out(Hi, stride[0], transposed) and Wo == ops.conv_out(Wi, stride[1], transposed)
+
+    out = torch.empty(B, Ho, Wo, C, device=dev)
+    slab = torch.zeros(ops.CONV_MAX_BLOCKS * 2 * C, device=dev)
+    a_src = (nhwc(ya).to(dev), ca.to(dev), not two_src)
+    b_src = (nhwc(yb).to(dev), cb.to(dev), False) if two_src else None
+    rows = ops.dw3x3_fwd(a_src, b_src, w.detach().to(dev), out, slab, transposed, B, Hi, Wi, C, stride)
+    close(nchw(out), ref, msg="forward")
+    s1, s2 = slab_stats(slab, rows, C)
+    close(s1, ref.detach().double().sum((0, 2, 3)), 1e-4, "sum")
+    close(s2, (ref.detach().double() ** 2).sum((0, 2, 3)), 1e-4, "sumsq")
+
+    # backward with a lazy gradient dy = s*dz + alpha*y + beta
+    dz = torch.randn(ref.shape, generator=g)
+    c3 = torch.randn(3 * C, generator=g) * 0.5
+    dy = c3[:C].view(1, C, 1, 1) * dz + c3[C:2 * C].view(1, C, 1, 1) * ref.detach() + c3[2 * C:].view(1, C, 1, 1)
+    ref.backward(dy)
+    g_in = torch.empty(B, Hi, Wi, C, device=dev)
+    dw = torch.empty(C, 1, 3, 3, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 10 * C, device=dev)
+    ops.dw3x3_bwd((nhwc(dz).to(dev), out, c3.to(dev)), a_src, b_src, w.detach().to(dev), g_in, dw, scratch,
+                  transposed, B, Hi, Wi, C, stride)
+    close(nchw(g_in), a_in.grad, msg="dgrad")
+    close(dw, w.grad, 1e-4, "wgrad")
+
+
+@pytest.mark.parametrize("K,N,npix,two_src", [
+    (32, 16, 1000, False), (16, 48, 777, False), (48, 24, 513, False), (24, 72, 300, False),
+    (72, 32, 129, False), (32, 96, 64, False), (96, 64, 55, False), (64, 192, 110, True),
+    (192, 32, 99, False), (32, 96, 50, True), (96, 24, 333, False), (24, 72, 200, True),
+    (72, 16, 5000, False), (16, 32, 4097, False),
+])
+def test_pointwise(dev, K, N, npix, two_src):
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(K * 1000 + N)
+    ya = torch.randn(npix, K, generator=g)
+    ca = rand_coef(K, g)
+    yb = torch.randn(npix, K, generator=g) if two_src else None
+    cb = rand_coef(K, g) if two_src else None
+    w = (torch.randn(N, K, generator=g) * 0.2).requires_grad_(True)
+    relu_a = not two_src
+
+    def lz(y, c, relu6):
+        v = y * c[:K] + c[K:2 * K]
+        return F.relu6(v) if relu6 else v
+    a_in = lz(ya, ca, relu_a)
+    if two_src:
+        a_in = a_in + lz(yb, cb, False)
+    a_in.requires_grad_(True)
+    ref = a_in @ w.t()
+    out = torch.empty(npix, N, device=dev)
+    slab = torch.zeros(1024 * 2 * N, device=dev)
+    a_src = (ya.to(dev), ca.to(dev), relu_a)
+    b_src = (yb.to(dev), cb.to(dev), False) if two_src else None
+    rows = ops.pw_fwd(a_src, b_src, w.detach().to(dev), out, slab, npix, K, N)
+    close(out, ref, msg="forward")
+    s1, s2 = slab_stats(slab, rows, N)
+    close(s1, ref.detach().double().sum(0), 1e-4, "sum")
+    close(s2, (ref.detach().double() ** 2).sum(0), 1e-4, "sumsq")
+
+    dz = torch.randn(npix, N, generator=g)
+    c3 = torch.randn(3 * N, generator=g) * 0.5
+    dy = c3[:N] * dz + c3[N:2 * N] * ref.detach() + c3[2 * N:]
+    ref.backward(dy)
+    other = torch.randn(npix, K, generator=g)
+    g_in = torch.empty(npix, K, device=dev)
+    grad = (dz.to(dev), out, c3.to(dev))
+    ops.pw_dgrad(grad, w.detach().to(dev), other.to(dev), g_in, npix, N, K)
+    close(g_in, a_in.grad + other, msg="dgrad+add")
+    ops.pw_dgrad(grad, w.detach().to(dev), None, g_in, npix, N, K)
+    close(g_in, a_in.grad, msg="dgrad")
+    dw = torch.empty(N, K, device=dev)
+    scratch = torch.empty(ops.PW_WGRAD_MAX_BLOCKS * N * K, device=dev)
+    ops.pw_wgrad(grad, a_src, b_src, dw, scratch, npix, N, K)
+    close(dw, w.grad, 1e-4, "wgrad")
+    # plain (coefficient-free) gradient path
+    ops.pw_dgrad((dz.to(dev), None, None), w.detach().to(dev), None, g_in, npix, N, K)
+    close(g_in, dz @ w.detach(), msg="dgrad plain")
+
+
+@pytest.mark.parametrize("B,H,W,hp,wp", [(2, 161, 51, 0, 14), (1, 33, 20, 3, 5), (3, 17, 17, 0, 0)])
+def test_first_conv(dev, B, H, W, hp, wp):
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(H)
+    C, stride = 32, (2, 2)
+    lm = torch.randn(B, 1, H, W, generator=g) * 3
+    mx = lm.abs().reshape(B, -1).max(1)[0]
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    x = F.pad(lm / (mx + 1e-6).view(B, 1, 1, 1), (wp, 0, hp, 0), value=-1.0)
+    ref = F.conv2d(x, w, stride=stride, padding=1)
+    Ho, Wo = ref.shape[-2:]
+    out = torch.empty(B, Ho, Wo, C, device=dev)
+    slab = torch.zeros(ops.CONV_MAX_BLOCKS * 2 * C, device=dev)
+    lm_d, mx_d = lm[:, 0].contiguous().to(dev), mx.to(dev)
+    rows = ops.first_conv_fwd(lm_d, mx_d, w.detach().to(dev), out, slab, B, H, W, hp, wp, -1.0, C, stride)
+    close(nchw(out), ref, msg="forward")
+    s1, s2 = slab_stats(slab, rows, C)
+    close(s1, ref.detach().double().sum((0, 2, 3)), 1e-4, "sum")
+    dz = torch.randn(ref.shape, generator=g)
+    ref.backward(dz)
+    dw = torch.empty(C, 1, 3, 3, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 10 * C, device=dev)
+    ops.first_conv_wgrad((nhwc(dz).to(dev), None, None), lm_d, mx_d, dw, scratch, B, H, W, hp, wp, -1.0, C, stride)
+    close(dw, w.grad, 1e-4, "wgrad")
+
+
+@pytest.mark.parametrize("B,Hi,Wi,H,W", [(2, 81, 33, 161, 51), (1, 9, 6, 17, 11), (2, 5, 5, 9, 9)])
+def test_last_convT(dev, B, Hi, Wi, H, W):
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(Hi)
+    C, stride = 32, (2, 2)
+    ya, yb = torch.randn(B, C, Hi, Wi, generator=g), torch.randn(B, C, Hi, Wi, generator=g)
+    ca, cb = rand_coef(C, g), rand_coef(C, g)
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    bias = torch.tensor([0.05], requires_grad=True)
+    lm = torch.randn(B, 1, H, W, generator=g) * 3
+    mx = (lm.abs().reshape(B, -1).max(1)[0] + 1e-6).view(B, 1, 1, 1)
+    a_in = (lazy_ref(ya, ca, False) + lazy_ref(yb, cb, True)).requires_grad_(True)
+    filt = F.conv_transpose2d(a_in, w, bias, stride=stride, padding=1)[:, :, -H:, -W:]
+    enh_ref = (lm / mx + filt).clamp(-1, 1) * mx
+    assert ((lm / mx + filt).abs() > 1).any(), "test should exercise the clamp"
+    enh = torch.empty(B, H, W, device=dev)
+    f_out = torch.empty(B, H, W, device=dev)
+    a_src, b_src = (nhwc(ya).to(dev), ca.to(dev), False), (nhwc(yb).to(dev), cb.to(dev), True)
+    lm_d, mx_d = lm[:, 0].contiguous().to(dev), lm.abs().reshape(B, -1).max(1)[0].to(dev)
+    ops.last_convT_fwd(a_src, b_src, w.detach().to(dev), bias.detach().to(dev), lm_d, mx_d, enh, f_out, B, Hi, Wi, C, stride, H, W)
+    close(f_out, filt[:, 0], msg="filters")
+    close(enh, enh_ref[:, 0], msg="enhanced")
+    d_enh = torch.randn(B, 1, H, W, generator=g)
+    enh_ref.backward(d_enh)
+    g_in = torch.empty(B, Hi, Wi, C, device=dev)
+    dw = torch.empty(C, 1, 3, 3, device=dev)
+    db = torch.empty(1, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 10 * C, device=dev)
+    ops.last_convT_bwd(d_enh[:, 0].contiguous().to(dev), enh, mx_d, a_src, b_src, w.detach().to(dev), g_in, dw, db, scratch,
+                       B, Hi, Wi, C, stride, H, W)
+    close(nchw(g_in), a_in.grad, msg="dgrad")
+    close(dw, w.grad, 1e-4, "wgrad")
+    close(db, bias.grad, 1e-4, "bias grad")
+
+
+@pytest.mark.parametrize("C,relu6,two", [(32, True, True), (48, True, False), (24, False, True), (192, True, False)])
+def test_batchnorm_train(dev, C, relu6, two):
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 3, 7, 9
+    npix = B * H * W
+    y = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.7).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g) * 0.1, 1 + torch.rand(C, generator=g)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    a = F.relu6(z) if relu6 else z
+    # forward finalize from (sum, sumsq) partials
+    yd = nhwc(y.detach()).to(dev)
+    slab = torch.stack([yd.view(npix, C).sum(0), (yd.view(npix, C) ** 2).sum(0)]).view(-1).contiguous()
+    coef = torch.empty(4 * C, device=dev)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    ops.bn_finalize_fwd(slab, 1, C, npix, gamma.detach().to(dev), beta.detach().to(dev), rm_d, rv_d, nbt, coef)
+    close(rm_d, rm_ref, 1e-5, "running mean")
+    close(rv_d, rv_ref, 1e-5, "running var")
+    assert int(nbt.item()) == 1
+    a_gpu = yd * coef[:C] + coef[C:2 * C]
+    close(nchw(a_gpu), z, 2e-5, "normalised")
+    # backward
+    g1 = torch.randn(a.shape, generator=g)
+    g2 = torch.randn(a.shape, generator=g) if two else None
+    a.backward(g1 + g2 if two else g1)
+    dz = torch.empty(B, H, W, C, device=dev)
+    dgamma, dbeta, coef3 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(3 * C, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 2 * C, device=dev)
+    ops.bn_bwd(nhwc(g1).to(dev), nhwc(g2).to(dev) if two else None, yd, coef, relu6, gamma.detach().to(dev), dz,
+               dgamma, dbeta, coef3, scratch, npix, C)
+    close(dgamma, gamma.grad, 1e-4, "dgamma")
+    close(dbeta, beta.grad, 1e-4, "dbeta")
+    dy = coef3[:C] * dz + coef3[C:2 * C] * yd + coef3[2 * C:]
+    close(nchw(dy), y.grad, 1e-4, "dy")
+    # eval-mode coefficients
+    ops.bn_coef_eval(C, gamma.detach().to(dev), beta.detach().to(dev), rm_d, rv_d, coef)
+    z_eval = F.batch_norm(y.detach(), rm_ref, rv_ref, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
+    close(nchw(yd * coef[:C] + coef[C:2 * C]), z_eval, 2e-5, "eval")
