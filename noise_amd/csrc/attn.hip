@@ -1,0 +1,824 @@
+// Bottleneck attention block of the denoiser (one post-LN Transformer encoder layer), gfx950.
+//
+// Replaces train/models.py:207-225 (TransformerEncoder.forward: LayerNorm, layer stack),
+// :60-89 (MultiHeadAttention), :27-37 (ScaledDotProductAttention incl. its dropout on the attention
+// weights, p = 0.1 in train mode), :102-112 (PositionwiseFeedForward) and :602 (VAD head on token 0).
+//
+// Tokens are the NHWC pixels of the bottleneck tensor, so token-wise steps work on flat tiles of 64
+// tokens (d_model = 64 lives in registers / LDS; these layers are <3 % of the step and VALU-sized),
+// and the attention core runs one workgroup per (clip, head) with K and V resident in LDS.
+#include "lazy.h"
+
+namespace {
+
+constexpr int D = 64;     // d_model
+constexpr int TT = 64;    // tokens per tile
+constexpr int XS = D + 4; // LDS row pitch of a token tile
+
+struct AttnDims {
+  long ntok;    // B * n
+  int n;        // tokens per clip
+  int heads, dk, hd;  // hd = heads*dk (<= 64)
+};
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// LayerNorm of one token row held in LDS (row of D floats), 4 lanes per token.  Writes xhat in place,
+// returns rstd.  Two-pass variance like torch.
+__device__ __forceinline__ float ln_row(float* row, int part, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < D / 4; ++k) s += row[part * (D / 4) + k];
+  const float mean = quad_sum(s) * (1.f / D);
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < D / 4; ++k) {
+    const float c = row[part * (D / 4) + k] - mean;
+    v += c * c;
+  }
+  const float rstd = rsqrtf(quad_sum(v) * (1.f / D) + eps);
+#pragma unroll
+  for (int k = 0; k < D / 4; ++k) row[part * (D / 4) + k] = (row[part * (D / 4) + k] - mean) * rstd;
+  return rstd;
+}
+
+// out[o] (o = part, part+4, ...) = sum_k x[k]*W[o*K+k] (+bias); x row and W in LDS.
+template <int K>
+__device__ __forceinline__ void row_linear(const float* xrow, const float* Wl, int O, int part, float* orow,
+                                           const float* bias, bool relu, const float* resid) {
+  float xr[K];
+#pragma unroll
+  for (int k = 0; k < K; k += 4) {
+    const float4 v = ld4(xrow + k);
+    xr[k] = v.x; xr[k + 1] = v.y; xr[k + 2] = v.z; xr[k + 3] = v.w;
+  }
+  for (int o = part; o < O; o += 4) {
+    float acc = bias ? bias[o] : 0.f;
+    const float* wr = Wl + o * K;
+#pragma unroll
+    for (int k = 0; k < K; k += 4) {
+      const float4 w = ld4(wr + k);
+      acc = fmaf(xr[k], w.x, acc);
+      acc = fmaf(xr[k + 1], w.y, acc);
+      acc = fmaf(xr[k + 2], w.z, acc);
+      acc = fmaf(xr[k + 3], w.w, acc);
+    }
+    if (resid) acc += resid[o];
+    orow[o] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+__device__ __forceinline__ void tile_store(float* g, const float* tile, int pitch, long tok0, long ntok, int width) {
+  // coalesced copy of a [TT][width] LDS tile (row pitch `pitch`) to global rows of `width` floats
+  for (int i = threadIdx.x; i < TT * width; i += 256) {
+    const int t = i / width, c = i - t * width;
+    if (tok0 + t < ntok) g[(tok0 + t) * width + c] = tile[t * pitch + c];
+  }
+}
+
+__device__ __forceinline__ void tile_load(float* tile, int pitch, const float* g, long tok0, long ntok, int width) {
+  for (int i = threadIdx.x; i < TT * width; i += 256) {
+    const int t = i / width, c = i - t * width;
+    tile[t * pitch + c] = (tok0 + t < ntok) ? g[(tok0 + t) * width + c] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A: x0 (lazy) -> xhat0, rstd0 -> x1 = g0*xhat0 + b0 -> qkv = x1 [Wq;Wk;Wv]^T
+__global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const float* __restrict__ ln_w,
+                                                           const float* __restrict__ ln_b, const float* __restrict__ wq,
+                                                           const float* __restrict__ wk, const float* __restrict__ wv,
+                                                           float* __restrict__ xhat0, float* __restrict__ rstd0,
+                                                           float* __restrict__ qkv, AttnDims d) {
+  extern __shared__ float lds[];
+  const int O = 3 * d.hd;
+  float* Wl = lds;                  // [O][D]
+  float* xs = Wl + O * D;           // [TT][XS]
+  float* os = xs + TT * XS;         // [TT][O]
+  float* lw = os + TT * O;          // [2][D]
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
+  for (int i = tid; i < O * D; i += 256) {
+    const int o = i / D, k = i - o * D;
+    const int which = o / d.hd, oo = o - which * d.hd;
+    const float* w = which == 0 ? wq : (which == 1 ? wk : wv);
+    Wl[i] = w[oo * D + k];
+  }
+  for (int i = tid; i < D; i += 256) {
+    lw[i] = ln_w[i];
+    lw[D + i] = ln_b[i];
+  }
+  for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
+    __syncthreads();
+    for (int i = tid; i < TT * D; i += 256) {
+      const int tt = i / D, c = i - tt * D;
+      float v = 0.f;
+      if (tok0 + tt < d.ntok) {
+        v = X.y[(tok0 + tt) * D + c];
+        if (X.coef) v = fmaf(v, X.coef[c], X.coef[D + c]);
+        if (X.relu6) v = relu6f(v);
+      }
+      xs[tt * XS + c] = v;
+    }
+    __syncthreads();
+    float* row = xs + t * XS;
+    const float rstd = ln_row(row, part, 1e-6f);
+    const bool valid = tok0 + t < d.ntok;
+    if (valid) {
+      if (part == 0) rstd0[tok0 + t] = rstd;
+#pragma unroll
+      for (int k = 0; k < D / 4; ++k) {
+        const int c = part * (D / 4) + k;
+        xhat0[(tok0 + t) * D + c] = row[c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      row[c] = fmaf(row[c], lw[c], lw[D + c]);
+    }
+    __syncthreads();  // also orders the 4 lanes of a token (same wave) and the weight staging
+    row_linear<D>(row, Wl, O, part, os + t * O, nullptr, false, nullptr);
+    __syncthreads();
+    tile_store(qkv, os, O, tok0, d.ntok, O);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B: attention core, one workgroup per (clip, head); one query per thread, K/V/Q of the head in LDS.
+__device__ __forceinline__ bool keep_elem(const unsigned char* keep, unsigned long long seed, float p_drop, long idx) {
+  if (keep) return keep[idx] != 0;
+  if (p_drop <= 0.f) return true;
+  // counter-based hash (splitmix64 finaliser) -> uniform in [0,1)
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.f / 16777216.f) >= p_drop;
+}
+
+constexpr int DKMAX = 16;
+
+__global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                            float* __restrict__ ml, const unsigned char* __restrict__ keep,
+                                                            unsigned long long seed, float p_drop, AttnDims d) {
+  extern __shared__ float lds[];
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+  float* ks = lds;            // [n][dk]
+  float* vs = ks + n * dk;    // [n][dk]
+  const long base = (long)b * n;
+  for (int i = threadIdx.x; i < n * dk; i += 256) {
+    const int j = i / dk, c = i - j * dk;
+    ks[i] = qkv[(base + j) * O + d.hd + h * dk + c];
+    vs[i] = qkv[(base + j) * O + 2 * d.hd + h * dk + c];
+  }
+  __syncthreads();
+  const float temp = sqrtf((float)dk);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float q[DKMAX];
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c) q[c] = c < dk ? qkv[(base + i) * O + h * dk + c] / temp : 0.f;
+    float m = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < DKMAX; ++c)
+        if (c < dk) s = fmaf(q[c], ks[j * dk + c], s);
+      m = fmaxf(m, s);
+    }
+    float l = 0.f, acc[DKMAX];
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c) acc[c] = 0.f;
+    const long mrow = (((long)b * d.heads + h) * n + i) * n;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < DKMAX; ++c)
+        if (c < dk) s = fmaf(q[c], ks[j * dk + c], s);
+      const float e = expf(s - m);
+      l += e;
+      if (keep_elem(keep, seed, p_drop, mrow + j)) {
+#pragma unroll
+        for (int c = 0; c < DKMAX; ++c)
+          if (c < dk) acc[c] = fmaf(e, vs[j * dk + c], acc[c]);
+      }
+    }
+    const float sc = inv_keep / l;
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c)
+      if (c < dk) o[(base + i) * d.hd + h * dk + c] = acc[c] * sc;
+    if (ml) {
+      ml[(((long)b * d.heads + h) * n + i) * 2] = m;
+      ml[(((long)b * d.heads + h) * n + i) * 2 + 1] = l;
+    }
+  }
+}
+
+// backward of the core: d_qkv from d_o.  Phase 1 (thread = query): D_i and dq_i.  Phase 2 (thread = key): dk_j, dv_j.
+__global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                            const float* __restrict__ ml, const unsigned char* __restrict__ keep,
+                                                            unsigned long long seed, float p_drop, float* __restrict__ d_qkv,
+                                                            AttnDims d) {
+  extern __shared__ float lds[];
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+  float* qs = lds;              // [n][dk]  (already divided by the temperature)
+  float* ks = qs + n * dk;
+  float* vs = ks + n * dk;
+  float* dos = vs + n * dk;     // [n][dk]
+  float* mm = dos + n * dk;     // [n] max
+  float* ll = mm + n;           // [n] 1/l
+  float* Dd = ll + n;           // [n] D_i
+  const long base = (long)b * n;
+  const float temp = sqrtf((float)dk);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  for (int i = threadIdx.x; i < n * dk; i += 256) {
+    const int j = i / dk, c = i - j * dk;
+    qs[i] = qkv[(base + j) * O + h * dk + c] / temp;
+    ks[i] = qkv[(base + j) * O + d.hd + h * dk + c];
+    vs[i] = qkv[(base + j) * O + 2 * d.hd + h * dk + c];
+    dos[i] = d_o[(base + j) * d.hd + h * dk + c];
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    mm[i] = ml[(((long)b * d.heads + h) * n + i) * 2];
+    ll[i] = 1.f / ml[(((long)b * d.heads + h) * n + i) * 2 + 1];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const long mrow = (((long)b * d.heads + h) * n + i) * n;
+    float Di = 0.f;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f, dp = 0.f;
+      for (int c = 0; c < dk; ++c) {
+        s = fmaf(qs[i * dk + c], ks[j * dk + c], s);
+        dp = fmaf(dos[i * dk + c], vs[j * dk + c], dp);
+      }
+      if (!keep_elem(keep, seed, p_drop, mrow + j)) dp = 0.f;
+      Di = fmaf(expf(s - mm[i]) * ll[i], dp * inv_keep, Di);
+    }
+    Dd[i] = Di;
+    float dq[DKMAX];
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c) dq[c] = 0.f;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f, dp = 0.f;
+      for (int c = 0; c < dk; ++c) {
+        s = fmaf(qs[i * dk + c], ks[j * dk + c], s);
+        dp = fmaf(dos[i * dk + c], vs[j * dk + c], dp);
+      }
+      if (!keep_elem(keep, seed, p_drop, mrow + j)) dp = 0.f;
+      const float p = expf(s - mm[i]) * ll[i];
+      const float ds = p * (dp * inv_keep - Di);
+#pragma unroll
+      for (int c = 0; c < DKMAX; ++c)
+        if (c < dk) dq[c] = fmaf(ds, ks[j * dk + c], dq[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c)
+      if (c < dk) d_qkv[(base + i) * O + h * dk + c] = dq[c] / temp;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float dkk[DKMAX], dvv[DKMAX];
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c) dkk[c] = dvv[c] = 0.f;
+    for (int i = 0; i < n; ++i) {
+      float s = 0.f, dp = 0.f;
+      for (int c = 0; c < dk; ++c) {
+        s = fmaf(qs[i * dk + c], ks[j * dk + c], s);
+        dp = fmaf(dos[i * dk + c], vs[j * dk + c], dp);
+      }
+      const bool kp = keep_elem(keep, seed, p_drop, (((long)b * d.heads + h) * n + i) * n + j);
+      const float p = expf(s - mm[i]) * ll[i];
+      const float pk = kp ? p * inv_keep : 0.f;
+      const float ds = p * ((kp ? dp * inv_keep : 0.f) - Dd[i]);
+#pragma unroll
+      for (int c = 0; c < DKMAX; ++c)
+        if (c < dk) {
+          dkk[c] = fmaf(ds, qs[i * dk + c], dkk[c]);
+          dvv[c] = fmaf(pk, dos[i * dk + c], dvv[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c)
+      if (c < dk) {
+        d_qkv[(base + j) * O + d.hd + h * dk + c] = dkk[c];
+        d_qkv[(base + j) * O + 2 * d.hd + h * dk + c] = dvv[c];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C: o, x1 -> y1 = o Wfc^T + x1 -> xhat1 -> x2 -> hdn = relu(x2 W1^T + b1) -> y2 = hdn W2^T + b2 + x2 -> xhat2 -> x3
+struct PostParams {
+  const float *fc, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b, *vad_w, *vad_b;
+};
+
+__global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restrict__ o, const float* __restrict__ xhat0,
+                                                            const float* __restrict__ ln0_w, const float* __restrict__ ln0_b,
+                                                            PostParams P, float* __restrict__ xhat1, float* __restrict__ rstd1,
+                                                            float* __restrict__ hdn, float* __restrict__ xhat2,
+                                                            float* __restrict__ rstd2, float* __restrict__ x3,
+                                                            float* __restrict__ vad, AttnDims d) {
+  extern __shared__ float lds[];
+  const int HD = d.hd;
+  float* Wfc = lds;                 // [D][HD]
+  float* W1 = Wfc + D * D;          // [D][D]
+  float* W2 = W1 + D * D;           // [D][D]
+  float* vec = W2 + D * D;          // ln0_w, ln0_b, ln1_w, ln1_b, b1, b2, ln2_w, ln2_b, vad_w  (9*D)
+  float* ta = vec + 9 * D;          // [TT][XS]
+  float* tb = ta + TT * XS;         // [TT][XS]
+  float* tc = tb + TT * XS;         // [TT][XS]
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
+  for (int i = tid; i < D * HD; i += 256) Wfc[i] = P.fc[i];
+  for (int i = tid; i < D * D; i += 256) {
+    W1[i] = P.w1[i];
+    W2[i] = P.w2[i];
+  }
+  for (int i = tid; i < D; i += 256) {
+    vec[i] = ln0_w[i]; vec[D + i] = ln0_b[i]; vec[2 * D + i] = P.ln1_w[i]; vec[3 * D + i] = P.ln1_b[i];
+    vec[4 * D + i] = P.b1[i]; vec[5 * D + i] = P.b2[i]; vec[6 * D + i] = P.ln2_w[i]; vec[7 * D + i] = P.ln2_b[i];
+    vec[8 * D + i] = P.vad_w[i];
+  }
+  for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
+    __syncthreads();
+    tile_load(ta, XS, o, tok0, d.ntok, HD);       // ta = o
+    tile_load(tb, XS, xhat0, tok0, d.ntok, D);    // tb = xhat0 -> x1
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      tb[t * XS + c] = fmaf(tb[t * XS + c], vec[c], vec[D + c]);
+    }
+    __syncthreads();
+    // tc = y1 = o Wfc^T + x1   (K = HD, padded reads are avoided by the generic loop below)
+    {
+      float* orow = tc + t * XS;
+      const float* xrow = ta + t * XS;
+      for (int oo = part; oo < D; oo += 4) {
+        float acc = 0.f;
+        for (int k = 0; k < HD; ++k) acc = fmaf(xrow[k], Wfc[oo * HD + k], acc);
+        orow[oo] = acc + tb[t * XS + oo];
+      }
+    }
+    __syncthreads();
+    const bool valid = tok0 + t < d.ntok;
+    float r1 = ln_row(tc + t * XS, part, 1e-6f);   // tc = xhat1
+    if (valid) {
+      if (part == 0) rstd1[tok0 + t] = r1;
+#pragma unroll
+      for (int k = 0; k < D / 4; ++k) {
+        const int c = part * (D / 4) + k;
+        xhat1[(tok0 + t) * D + c] = tc[t * XS + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      tc[t * XS + c] = fmaf(tc[t * XS + c], vec[2 * D + c], vec[3 * D + c]);   // tc = x2
+    }
+    __syncthreads();
+    row_linear<D>(tc + t * XS, W1, D, part, ta + t * XS, vec + 4 * D, true, nullptr);   // ta = hdn
+    __syncthreads();
+    tile_store(hdn, ta, XS, tok0, d.ntok, D);
+    row_linear<D>(ta + t * XS, W2, D, part, tb + t * XS, vec + 5 * D, false, tc + t * XS);  // tb = y2
+    __syncthreads();
+    float r2 = ln_row(tb + t * XS, part, 1e-6f);   // tb = xhat2
+    if (valid) {
+      if (part == 0) rstd2[tok0 + t] = r2;
+#pragma unroll
+      for (int k = 0; k < D / 4; ++k) {
+        const int c = part * (D / 4) + k;
+        const float xh = tb[t * XS + c];
+        xhat2[(tok0 + t) * D + c] = xh;
+        const float v = fmaf(xh, vec[6 * D + c], vec[7 * D + c]);
+        x3[(tok0 + t) * D + c] = v;
+        tb[t * XS + c] = v;
+      }
+    }
+    __syncthreads();
+    // VAD head on the first token of each clip
+    if (valid && part == 0 && (tok0 + t) % d.n == 0) {
+      float acc = P.vad_b[0];
+      for (int c = 0; c < D; ++c) acc = fmaf(tb[t * XS + c], vec[8 * D + c], acc);
+      vad[(tok0 + t) / d.n] = acc;
+    }
+  }
+}
+
+// dW[o0..o0+3][k0..k0+3] += sum_t dy[t][o] * x[t][k] over the tile (both tiles in LDS, pitch XS)
+__device__ __forceinline__ void acc_outer4(float (&a)[16], const float* dy, const float* x, int o0, int k0) {
+  for (int t = 0; t < TT; ++t) {
+    const float4 dv = ld4(dy + t * XS + o0);
+    const float4 xv = ld4(x + t * XS + k0);
+    a[0] = fmaf(dv.x, xv.x, a[0]); a[1] = fmaf(dv.x, xv.y, a[1]); a[2] = fmaf(dv.x, xv.z, a[2]); a[3] = fmaf(dv.x, xv.w, a[3]);
+    a[4] = fmaf(dv.y, xv.x, a[4]); a[5] = fmaf(dv.y, xv.y, a[5]); a[6] = fmaf(dv.y, xv.z, a[6]); a[7] = fmaf(dv.y, xv.w, a[7]);
+    a[8] = fmaf(dv.z, xv.x, a[8]); a[9] = fmaf(dv.z, xv.y, a[9]); a[10] = fmaf(dv.z, xv.z, a[10]); a[11] = fmaf(dv.z, xv.w, a[11]);
+    a[12] = fmaf(dv.w, xv.x, a[12]); a[13] = fmaf(dv.w, xv.y, a[13]); a[14] = fmaf(dv.w, xv.z, a[14]); a[15] = fmaf(dv.w, xv.w, a[15]);
+  }
+}
+
+__device__ __forceinline__ void store_outer4(float* dst, int ldk, const float (&a)[16], int o0, int k0) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[(o0 + r) * ldk + k0 + c] = a[r * 4 + c];
+}
+
+// LayerNorm backward on a tile: g (LDS, in/out: dL/d(ln out) -> dL/d(ln in)), xhat tile (LDS), gamma (LDS).
+// Also accumulates column sums for dgamma / dbeta into per-thread registers of threads c < D.
+__device__ __forceinline__ void ln_bwd_tile(float* g, const float* xh, const float* gamma, const float* rstd_g, long tok0,
+                                            long ntok, float& dgam, float& dbet) {
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
+  if (tid < D) {
+    float sg = 0.f, sb = 0.f;
+    for (int tt = 0; tt < TT; ++tt) {
+      const float gv = g[tt * XS + tid];
+      sg = fmaf(gv, xh[tt * XS + tid], sg);
+      sb += gv;
+    }
+    dgam += sg;
+    dbet += sb;
+  }
+  __syncthreads();
+  float a = 0.f, bsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < D / 4; ++k) {
+    const int c = part * (D / 4) + k;
+    const float gg = g[t * XS + c] * gamma[c];
+    a += gg;
+    bsum = fmaf(gg, xh[t * XS + c], bsum);
+  }
+  a = quad_sum(a) * (1.f / D);
+  bsum = quad_sum(bsum) * (1.f / D);
+  const float rs = (tok0 + t < ntok) ? rstd_g[tok0 + t] : 0.f;
+#pragma unroll
+  for (int k = 0; k < D / 4; ++k) {
+    const int c = part * (D / 4) + k;
+    g[t * XS + c] = rs * (g[t * XS + c] * gamma[c] - a - xh[t * XS + c] * bsum);
+  }
+}
+
+// slab row layout of attn_post_bwd (floats): dW2[D*D] dW1[D*D] dWfc[D*HD] then 7 vectors of D:
+// dln2_w dln2_b db2 db1 dln1_w dln1_b dvad_w, then dvad_b (1)
+__global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restrict__ g3, const float* __restrict__ d_vad,
+                                                            const float* __restrict__ o, const float* __restrict__ xhat1,
+                                                            const float* __restrict__ rstd1, const float* __restrict__ hdn,
+                                                            const float* __restrict__ xhat2, const float* __restrict__ rstd2,
+                                                            const float* __restrict__ x3, PostParams P,
+                                                            float* __restrict__ d_o, float* __restrict__ d_x1,
+                                                            float* __restrict__ slab, AttnDims d) {
+  extern __shared__ float lds[];
+  const int HD = d.hd;
+  float* WfcT = lds;                // [HD][D]  (transposed: d_o = dy1 Wfc)
+  float* W1T = WfcT + D * D;        // [D][D]   W1T[k][o] = W1[o][k]
+  float* W2T = W1T + D * D;
+  float* vec = W2T + D * D;         // ln1_w, ln2_w, vad_w, ln1_b  (4*D)
+  float* ta = vec + 4 * D;
+  float* tb = ta + TT * XS;
+  float* tc = tb + TT * XS;
+  float* td = tc + TT * XS;
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
+  for (int i = tid; i < D * HD; i += 256) {
+    const int oo = i / HD, k = i - oo * HD;
+    WfcT[k * D + oo] = P.fc[i];
+  }
+  for (int i = tid; i < D * D; i += 256) {
+    const int oo = i / D, k = i - oo * D;
+    W1T[k * D + oo] = P.w1[i];
+    W2T[k * D + oo] = P.w2[i];
+  }
+  for (int i = tid; i < D; i += 256) {
+    vec[i] = P.ln1_w[i]; vec[D + i] = P.ln2_w[i]; vec[2 * D + i] = P.vad_w[i]; vec[3 * D + i] = P.ln1_b[i];
+  }
+  float aW2[16], aW1[16], aFc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) aW2[e] = aW1[e] = aFc[e] = 0.f;
+  float dg2 = 0.f, db2ln = 0.f, dbias2 = 0.f, dbias1 = 0.f, dg1 = 0.f, db1ln = 0.f, dvw = 0.f, dvb = 0.f;
+  const int o0 = (tid >> 4) * 4, k0 = (tid & 15) * 4;      // 4x4 block of a DxD matrix
+  const bool fc_owner = k0 < HD;                            // HD is a multiple of 4
+
+  for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
+    __syncthreads();
+    tile_load(ta, XS, g3, tok0, d.ntok, D);       // ta = dL/dx3
+    tile_load(tb, XS, xhat2, tok0, d.ntok, D);    // tb = xhat2
+    tile_load(tc, XS, hdn, tok0, d.ntok, D);      // tc = hdn
+    __syncthreads();
+    // VAD head gradient enters at token 0 of each clip
+    if (tok0 + t < d.ntok && (tok0 + t) % d.n == 0) {
+      const float dv = d_vad[(tok0 + t) / d.n];
+#pragma unroll
+      for (int k = 0; k < D / 4; ++k) {
+        const int c = part * (D / 4) + k;
+        ta[t * XS + c] = fmaf(dv, vec[2 * D + c], ta[t * XS + c]);
+      }
+    }
+    if (tid < D) {   // dvad_w[c] += sum over clips dv * x3[token0][c]
+      for (int tt = 0; tt < TT; ++tt)
+        if (tok0 + tt < d.ntok && (tok0 + tt) % d.n == 0) {
+          const float dv = d_vad[(tok0 + tt) / d.n];
+          dvw = fmaf(dv, x3[(tok0 + tt) * D + tid], dvw);
+          if (tid == 0) dvb += dv;
+        }
+    }
+    __syncthreads();
+    ln_bwd_tile(ta, tb, vec + D, rstd2, tok0, d.ntok, dg2, db2ln);   // ta = dy2
+    __syncthreads();
+    if (tid < D) {
+      float s = 0.f;
+      for (int tt = 0; tt < TT; ++tt) s += ta[tt * XS + tid];
+      dbias2 += s;
+    }
+    acc_outer4(aW2, ta, tc, o0, k0);                                   // dW2 += dy2^T hdn
+    // td = d_pre = (dy2 W2) * [hdn > 0]
+    row_linear<D>(ta + t * XS, W2T, D, part, td + t * XS, nullptr, false, nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      if (!(tc[t * XS + c] > 0.f)) td[t * XS + c] = 0.f;
+    }
+    __syncthreads();
+    tile_load(tb, XS, xhat1, tok0, d.ntok, D);    // tb = xhat1
+    __syncthreads();
+    if (tid < D) {
+      float s = 0.f;
+      for (int tt = 0; tt < TT; ++tt) s += td[tt * XS + tid];
+      dbias1 += s;
+    }
+    // tc = x2 = ln1_w*xhat1 + ln1_b
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      tc[t * XS + c] = fmaf(tb[t * XS + c], vec[c], vec[3 * D + c]);
+    }
+    __syncthreads();
+    acc_outer4(aW1, td, tc, o0, k0);                                   // dW1 += d_pre^T x2
+    __syncthreads();
+    // tc = d_x2 = dy2 + d_pre W1
+    row_linear<D>(td + t * XS, W1T, D, part, tc + t * XS, nullptr, false, ta + t * XS);
+    __syncthreads();
+    ln_bwd_tile(tc, tb, vec, rstd1, tok0, d.ntok, dg1, db1ln);        // tc = dy1
+    __syncthreads();
+    tile_store(d_x1, tc, XS, tok0, d.ntok, D);                          // residual branch of x1
+    tile_load(ta, XS, o, tok0, d.ntok, HD);                             // ta = o (cols >= HD are stale: masked below)
+    __syncthreads();
+    if (fc_owner) acc_outer4(aFc, tc, ta, o0, k0);                      // dWfc += dy1^T o
+    // td = d_o = dy1 Wfc  (HD outputs)
+    row_linear<D>(tc + t * XS, WfcT, HD, part, td + t * XS, nullptr, false, nullptr);
+    __syncthreads();
+    tile_store(d_o, td, XS, tok0, d.ntok, HD);
+  }
+  float* row = slab + (size_t)blockIdx.x * (2 * D * D + D * HD + 7 * D + 1);
+  store_outer4(row, D, aW2, o0, k0);
+  store_outer4(row + D * D, D, aW1, o0, k0);
+  if (fc_owner) store_outer4(row + 2 * D * D, HD, aFc, o0, k0);
+  if (tid < D) {
+    float* v = row + 2 * D * D + D * HD;
+    v[tid] = dg2; v[D + tid] = db2ln; v[2 * D + tid] = dbias2; v[3 * D + tid] = dbias1;
+    v[4 * D + tid] = dg1; v[5 * D + tid] = db1ln; v[6 * D + tid] = dvw;
+    if (tid == 0) v[7 * D] = dvb;
+  }
+}
+
+// A': d_qkv, d_x1 (partial) -> d_x1 += d_qkv Wqkv; dWqkv += d_qkv^T x1; LN0 backward -> d_x0
+// slab row: dWqkv[O*D] dln0_w[D] dln0_b[D]
+__global__ __launch_bounds__(256) void attn_pre_bwd_kernel(const float* __restrict__ d_qkv, const float* __restrict__ d_x1,
+                                                           const float* __restrict__ xhat0, const float* __restrict__ rstd0,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                           const float* __restrict__ wq, const float* __restrict__ wk,
+                                                           const float* __restrict__ wv, float* __restrict__ d_x0,
+                                                           float* __restrict__ slab, AttnDims d) {
+  extern __shared__ float lds[];
+  const int O = 3 * d.hd;
+  float* Wl = lds;                  // [O][D] (row o = output feature o of the fused qkv projection)
+  float* dq = Wl + O * D;           // [TT][O]
+  float* ta = dq + TT * O;          // [TT][XS]
+  float* tb = ta + TT * XS;
+  float* lw = tb + TT * XS;         // [2][D]
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
+  for (int i = tid; i < O * D; i += 256) {
+    const int o = i / D, k = i - o * D;
+    const int which = o / d.hd, oo = o - which * d.hd;
+    const float* w = which == 0 ? wq : (which == 1 ? wk : wv);
+    Wl[i] = w[oo * D + k];
+  }
+  for (int i = tid; i < D; i += 256) {
+    lw[i] = ln_w[i];
+    lw[D + i] = ln_b[i];
+  }
+  // each thread owns 4x4 blocks of dWqkv: block id = tid, tid+256, ... over (O/4) x (D/4) blocks
+  const int nblk = (O / 4) * (D / 4);
+  constexpr int MAXB = 4;
+  float aW[MAXB][16];
+#pragma unroll
+  for (int r = 0; r < MAXB; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) aW[r][e] = 0.f;
+  float dg0 = 0.f, db0 = 0.f;
+
+  for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
+    __syncthreads();
+    tile_load(dq, O, d_qkv, tok0, d.ntok, O);
+    tile_load(ta, XS, d_x1, tok0, d.ntok, D);     // ta = d_x1 (residual part)
+    tile_load(tb, XS, xhat0, tok0, d.ntok, D);    // tb = xhat0
+    __syncthreads();
+    // ta += d_qkv Wqkv
+    {
+      float acc[D / 4];
+#pragma unroll
+      for (int k = 0; k < D / 4; ++k) acc[k] = ta[t * XS + part * (D / 4) + k];
+      for (int o = 0; o < O; ++o) {
+        const float g = dq[t * O + o];
+#pragma unroll
+        for (int k = 0; k < D / 4; ++k) acc[k] = fmaf(g, Wl[o * D + part * (D / 4) + k], acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < D / 4; ++k) ta[t * XS + part * (D / 4) + k] = acc[k];
+    }
+    // dWqkv += d_qkv^T x1, x1 = ln_w*xhat0 + ln_b
+#pragma unroll
+    for (int r = 0; r < MAXB; ++r) {
+      const int blk = tid + r * 256;
+      if (blk < nblk) {
+        const int o0 = (blk / (D / 4)) * 4, k0 = (blk % (D / 4)) * 4;
+        for (int tt = 0; tt < TT; ++tt) {
+          const float4 dv = ld4(dq + tt * O + o0);
+          float4 xv = ld4(tb + tt * XS + k0);
+          xv = fma4(xv, ld4(lw + k0), ld4(lw + D + k0));
+          if (tok0 + tt >= d.ntok) xv = f4(0.f);
+          float* a = aW[r];
+          a[0] = fmaf(dv.x, xv.x, a[0]); a[1] = fmaf(dv.x, xv.y, a[1]); a[2] = fmaf(dv.x, xv.z, a[2]); a[3] = fmaf(dv.x, xv.w, a[3]);
+          a[4] = fmaf(dv.y, xv.x, a[4]); a[5] = fmaf(dv.y, xv.y, a[5]); a[6] = fmaf(dv.y, xv.z, a[6]); a[7] = fmaf(dv.y, xv.w, a[7]);
+          a[8] = fmaf(dv.z, xv.x, a[8]); a[9] = fmaf(dv.z, xv.y, a[9]); a[10] = fmaf(dv.z, xv.z, a[10]); a[11] = fmaf(dv.z, xv.w, a[11]);
+          a[12] = fmaf(dv.w, xv.x, a[12]); a[13] = fmaf(dv.w, xv.y, a[13]); a[14] = fmaf(dv.w, xv.z, a[14]); a[15] = fmaf(dv.w, xv.w, a[15]);
+        }
+      }
+    }
+    __syncthreads();
+    ln_bwd_tile(ta, tb, lw, rstd0, tok0, d.ntok, dg0, db0);
+    __syncthreads();
+    tile_store(d_x0, ta, XS, tok0, d.ntok, D);
+  }
+  float* row = slab + (size_t)blockIdx.x * (O * D + 2 * D);
+#pragma unroll
+  for (int r = 0; r < MAXB; ++r) {
+    const int blk = tid + r * 256;
+    if (blk < nblk) {
+      const int o0 = (blk / (D / 4)) * 4, k0 = (blk % (D / 4)) * 4;
+      store_outer4(row, D, aW[r], o0, k0);
+    }
+  }
+  if (tid < D) {
+    row[O * D + tid] = dg0;
+    row[O * D + D + tid] = db0;
+  }
+}
+
+__global__ void attn_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols, float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncols) return;
+  double s = 0.0;
+  for (int b = 0; b < nrows; ++b) s += (double)slab[(size_t)b * ncols + j];
+  out[j] = (float)s;
+}
+
+int check_attn(const char* who, long ntok, int n, int d_model, int heads, int dk) {
+  NOISE_REQUIRE(d_model == D, "%s: d_model=%d unsupported (this build handles %d)", who, d_model, D);
+  NOISE_REQUIRE(heads > 0 && dk > 0 && dk <= DKMAX && heads * dk <= D && (heads * dk) % 4 == 0,
+                "%s: heads=%d d_k=%d unsupported", who, heads, dk);
+  NOISE_REQUIRE(n > 0 && ntok > 0 && ntok % n == 0, "%s: %ld tokens is not a multiple of n=%d", who, ntok, n);
+  return 0;
+}
+
+constexpr int ATTN_MAX_BLOCKS = 256;
+
+}  // namespace
+
+NOISE_EXPORT int noise_attn_max_blocks(void) { return ATTN_MAX_BLOCKS; }
+
+NOISE_EXPORT int noise_attn_pre_fwd(const float* x_y, const float* x_coef, int x_relu6, const float* ln_w,
+                                    const float* ln_b, const float* wq, const float* wk, const float* wv, float* xhat0,
+                                    float* rstd0, float* qkv, long ntok, int n, int d_model, int heads, int dk,
+                                    void* stream) {
+  if (check_attn("noise_attn_pre_fwd", ntok, n, d_model, heads, dk)) return -1;
+  NOISE_REQUIRE(x_y && ln_w && ln_b && wq && wk && wv && xhat0 && rstd0 && qkv, "noise_attn_pre_fwd: null pointer");
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  const int O = 3 * d.hd;
+  const size_t smem = (size_t)(O * D + TT * XS + TT * O + 2 * D) * sizeof(float);
+  LazySrc X{x_y, x_coef, x_relu6};
+  NOISE_ALLOW_LDS(attn_pre_fwd_kernel, smem);
+  hipLaunchKernelGGL(attn_pre_fwd_kernel, dim3(noise_grid(ntok, TT, 1024)), dim3(256), smem, (hipStream_t)stream, X, ln_w,
+                     ln_b, wq, wk, wv, xhat0, rstd0, qkv, d);
+  NOISE_CHECK_LAUNCH("noise_attn_pre_fwd");
+  return 0;
+}
+
+// keep (optional): uint8 [B][heads][n][n] keep-mask; otherwise a counter-based hash of (seed, index) with
+// drop probability p_drop (0 disables dropout).  ml (optional unless training): [B][heads][n][2] = (max, sum).
+NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, const unsigned char* keep,
+                                     unsigned long long seed, float p_drop, long ntok, int n, int d_model, int heads,
+                                     int dk, void* stream) {
+  if (check_attn("noise_attn_core_fwd", ntok, n, d_model, heads, dk)) return -1;
+  NOISE_REQUIRE(qkv && o, "noise_attn_core_fwd: null pointer");
+  NOISE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "noise_attn_core_fwd: p_drop=%f out of range", p_drop);
+  const size_t smem = (size_t)2 * n * dk * sizeof(float);
+  NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_fwd: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  NOISE_ALLOW_LDS(attn_core_fwd_kernel, smem);
+  hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)(ntok / n) * heads), dim3(256), smem, (hipStream_t)stream, qkv, o,
+                     ml, keep, seed, p_drop, d);
+  NOISE_CHECK_LAUNCH("noise_attn_core_fwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_attn_core_bwd(const float* qkv, const float* d_o, const float* ml, const unsigned char* keep,
+                                     unsigned long long seed, float p_drop, float* d_qkv, long ntok, int n, int d_model,
+                                     int heads, int dk, void* stream) {
+  if (check_attn("noise_attn_core_bwd", ntok, n, d_model, heads, dk)) return -1;
+  NOISE_REQUIRE(qkv && d_o && ml && d_qkv, "noise_attn_core_bwd: null pointer");
+  const size_t smem = (size_t)(4 * n * dk + 3 * n) * sizeof(float);
+  NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_bwd: n=%d tokens per clip exceed the LDS limit", n);
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  NOISE_ALLOW_LDS(attn_core_bwd_kernel, smem);
+  hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)(ntok / n) * heads), dim3(256), smem, (hipStream_t)stream, qkv,
+                     d_o, ml, keep, seed, p_drop, d_qkv, d);
+  NOISE_CHECK_LAUNCH("noise_attn_core_bwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_attn_post_fwd(const float* o, const float* xhat0, const float* ln0_w, const float* ln0_b,
+                                     const float* fc, const float* ln1_w, const float* ln1_b, const float* w1,
+                                     const float* b1, const float* w2, const float* b2, const float* ln2_w,
+                                     const float* ln2_b, const float* vad_w, const float* vad_b, float* xhat1,
+                                     float* rstd1, float* hdn, float* xhat2, float* rstd2, float* x3, float* vad,
+                                     long ntok, int n, int d_model, int heads, int dk, void* stream) {
+  if (check_attn("noise_attn_post_fwd", ntok, n, d_model, heads, dk)) return -1;
+  NOISE_REQUIRE(o && xhat0 && ln0_w && ln0_b && fc && ln1_w && ln1_b && w1 && b1 && w2 && b2 && ln2_w && ln2_b && vad_w &&
+                    vad_b && xhat1 && rstd1 && hdn && xhat2 && rstd2 && x3 && vad,
+                "noise_attn_post_fwd: null pointer");
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  PostParams P{fc, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, vad_w, vad_b};
+  const size_t smem = (size_t)(3 * D * D + 9 * D + 3 * TT * XS) * sizeof(float);
+  NOISE_ALLOW_LDS(attn_post_fwd_kernel, smem);
+  hipLaunchKernelGGL(attn_post_fwd_kernel, dim3(noise_grid(ntok, TT, 1024)), dim3(256), smem, (hipStream_t)stream, o, xhat0,
+                     ln0_w, ln0_b, P, xhat1, rstd1, hdn, xhat2, rstd2, x3, vad, d);
+  NOISE_CHECK_LAUNCH("noise_attn_post_fwd");
+  return 0;
+}
+
+// grads: flat output [dW2 D*D | dW1 D*D | dWfc D*hd | dln2_w | dln2_b | db2 | db1 | dln1_w | dln1_b | dvad_w | dvad_b(1)]
+// scratch: noise_attn_max_blocks() rows of that size.
+NOISE_EXPORT int noise_attn_post_bwd(const float* g3, const float* d_vad, const float* o, const float* xhat1,
+                                     const float* rstd1, const float* hdn, const float* xhat2, const float* rstd2,
+                                     const float* x3, const float* fc, const float* ln1_w, const float* ln1_b,
+                                     const float* w1, const float* w2, const float* ln2_w, const float* vad_w, float* d_o,
+                                     float* d_x1, float* grads, float* scratch, long ntok, int n, int d_model, int heads,
+                                     int dk, void* stream) {
+  if (check_attn("noise_attn_post_bwd", ntok, n, d_model, heads, dk)) return -1;
+  NOISE_REQUIRE(g3 && d_vad && o && xhat1 && rstd1 && hdn && xhat2 && rstd2 && x3 && fc && ln1_w && ln1_b && w1 && w2 &&
+                    ln2_w && vad_w && d_o && d_x1 && grads && scratch,
+                "noise_attn_post_bwd: null pointer");
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  PostParams P{fc, ln1_w, ln1_b, w1, nullptr, w2, nullptr, ln2_w, nullptr, vad_w, nullptr};
+  const int ncols = 2 * D * D + D * d.hd + 7 * D + 1;
+  const int grid = noise_grid(ntok, TT, ATTN_MAX_BLOCKS);
+  const size_t smem = (size_t)(3 * D * D + 4 * D + 4 * TT * XS) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  NOISE_ALLOW_LDS(attn_post_bwd_kernel, smem);
+  hipLaunchKernelGGL(attn_post_bwd_kernel, dim3(grid), dim3(256), smem, st, g3, d_vad, o, xhat1, rstd1, hdn, xhat2, rstd2, x3,
+                     P, d_o, d_x1, scratch, d);
+  NOISE_CHECK_LAUNCH("noise_attn_post_bwd");
+  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, 256)), dim3(256), 0, st, scratch, grid, ncols, grads);
+  NOISE_CHECK_LAUNCH("noise_attn_post_bwd/reduce");
+  return 0;
+}
+
+// grads: flat output [dWq hd*D | dWk hd*D | dWv hd*D | dln0_w D | dln0_b D]
+NOISE_EXPORT int noise_attn_pre_bwd(const float* d_qkv, const float* d_x1, const float* xhat0, const float* rstd0,
+                                    const float* ln_w, const float* ln_b, const float* wq, const float* wk,
+                                    const float* wv, float* d_x0, float* grads, float* scratch, long ntok, int n,
+                                    int d_model, int heads, int dk, void* stream) {
+  if (check_attn("noise_attn_pre_bwd", ntok, n, d_model, heads, dk)) return -1;
+  NOISE_REQUIRE(d_qkv && d_x1 && xhat0 && rstd0 && ln_w && ln_b && wq && wk && wv && d_x0 && grads && scratch,
+                "noise_attn_pre_bwd: null pointer");
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  const int O = 3 * d.hd;
+  NOISE_REQUIRE((O / 4) * (D / 4) <= 4 * 256, "noise_attn_pre_bwd: projection too wide");
+  const int ncols = O * D + 2 * D;
+  const int grid = noise_grid(ntok, TT, ATTN_MAX_BLOCKS);
+  const size_t smem = (size_t)(O * D + TT * O + 2 * TT * XS + 2 * D) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  NOISE_ALLOW_LDS(attn_pre_bwd_kernel, smem);
+  hipLaunchKernelGGL(attn_pre_bwd_kernel, dim3(grid), dim3(256), smem, st, d_qkv, d_x1, xhat0, rstd0, ln_w, ln_b, wq, wk, wv,
+                     d_x0, scratch, d);
+  NOISE_CHECK_LAUNCH("noise_attn_pre_bwd");
+  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, 256)), dim3(256), 0, st, scratch, grid, ncols, grads);
+  NOISE_CHECK_LAUNCH("noise_attn_pre_bwd/reduce");
+  return 0;
+}

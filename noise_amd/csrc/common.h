@@ -28,6 +28,14 @@ void noise_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// Kernels that stage more than 64 KiB of dynamic LDS opt in explicitly (gfx950 has 160 KiB per CU).
+#define NOISE_ALLOW_LDS(kernel, bytes)                                                                         \
+  do {                                                                                                         \
+    if ((bytes) > 64 * 1024)                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)(bytes));                                                                 \
+  } while (0)
+
 static inline int noise_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Memory-bound elementwise/reduction kernels: cap the grid and grid-stride the rest.

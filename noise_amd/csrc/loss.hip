@@ -1,0 +1,203 @@
+// Training losses of the spectral model and their gradients (train/models.py:776-790), gfx950.
+//
+//   spectral  = mean |enh - clean_logmag|                                  (:777)
+//   vad       = mean BCE-with-logits(vad, [count(|clean| > 0) >= 160])      (:780-783)
+//   waveform  = l1_loss((B,1,1,L), (B,L)) which BROADCASTS to (B,1,B,L):    (:786-787)
+//               mean over all (i, j, t) of |enh_wave[i][t] - clean_wave[j][t]|
+//   loss      = waveform + spectral + vad                                   (:790)
+// All reductions are per-workgroup partials folded by one finalize kernel (no atomics, reproducible).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+// partial[blockIdx] = sum |enh - clm|;  d_enh = sign(enh - clm) * scale
+__global__ __launch_bounds__(256) void spectral_l1_kernel(const float* __restrict__ enh, const float* __restrict__ clm,
+                                                          long n, float scale, float* __restrict__ d_enh,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = enh[i] - clm[i];
+    s += (double)fabsf(d);
+    if (d_enh) d_enh[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+  }
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// label[b] = count(|clean[b]| > 0) >= min_active
+__global__ __launch_bounds__(256) void vad_label_kernel(const float* __restrict__ clean, int L, int min_active,
+                                                        float* __restrict__ label) {
+  __shared__ int red[4];
+  int c = 0;
+  const float* x = clean + (size_t)blockIdx.x * L;
+  for (int i = threadIdx.x; i < L; i += 256) c += fabsf(x[i]) > 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) label[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) >= min_active ? 1.f : 0.f;
+}
+
+// Cross-pair waveform L1.  One workgroup = WT consecutive time samples of every clip.
+//   pair_abs partial, and sgn[i][t] = sum_j sign(w_i[t] - c_j[t])
+constexpr int WT = 16;     // time samples per workgroup
+constexpr int WJ = 1024;   // clean rows staged per LDS fill
+
+__global__ __launch_bounds__(256) void wave_pair_l1_kernel(const float* __restrict__ w, const float* __restrict__ c, int B,
+                                                           int L, float scale, float* __restrict__ d_w,
+                                                           double* __restrict__ partial) {
+  extern __shared__ float cs[];   // [WJ][WT]
+  __shared__ double red[4];
+  const int tid = threadIdx.x, tl = tid & (WT - 1), il = tid / WT;   // 16 time lanes x 16 clip lanes
+  const int t0 = blockIdx.x * WT;
+  const int t = t0 + tl;
+  const bool tv = t < L;
+  double total = 0.0;
+  const int ni = (B + 15) / 16;   // clips per clip lane
+  for (int i0 = 0; i0 < ni; i0 += 4) {
+    // this thread owns clips il + 16*(i0 .. i0+3)
+    float wv[4], ab[4], sg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = il + 16 * (i0 + r);
+      wv[r] = (tv && i0 + r < ni && i < B) ? w[(size_t)i * L + t] : 0.f;
+      ab[r] = 0.f;
+      sg[r] = 0.f;
+    }
+    for (int j0 = 0; j0 < B; j0 += WJ) {
+      const int nj = min(WJ, B - j0);
+      __syncthreads();
+      for (int e = tid; e < nj * WT; e += 256) {
+        const int j = e / WT, tt = e - j * WT;
+        cs[e] = (t0 + tt < L) ? c[(size_t)(j0 + j) * L + t0 + tt] : 0.f;
+      }
+      __syncthreads();
+      for (int j = 0; j < nj; ++j) {
+        const float cv = cs[j * WT + tl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = wv[r] - cv;
+          ab[r] += fabsf(d);
+          sg[r] += (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = il + 16 * (i0 + r);
+      if (tv && i0 + r < ni && i < B) {
+        total += (double)ab[r];
+        if (d_w) d_w[(size_t)i * L + t] = sg[r] * scale;
+      }
+    }
+  }
+  total = block_sum_d(total, red);
+  if (tid == 0) partial[blockIdx.x] = total;
+}
+
+// out[0..3] = loss, vad_loss, waveform_loss, spectral_loss;  d_vad[b] = (sigmoid(x) - y)/B
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ spec_partial, int n_spec,
+                                                            double spec_count, const double* __restrict__ wave_partial,
+                                                            int n_wave, double wave_count, const float* __restrict__ vad,
+                                                            const float* __restrict__ label, int B, float* __restrict__ d_vad,
+                                                            float* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0, wv = 0.0, bce = 0.0;
+  for (int i = threadIdx.x; i < n_spec; i += 256) s += spec_partial[i];
+  for (int i = threadIdx.x; i < n_wave; i += 256) wv += wave_partial[i];
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float x = vad[b], y = label[b];
+    bce += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+    if (d_vad) d_vad[b] = (1.f / (1.f + expf(-x)) - y) / (float)B;
+  }
+  s = block_sum_d(s, red);
+  wv = block_sum_d(wv, red);
+  bce = block_sum_d(bce, red);
+  if (threadIdx.x == 0) {
+    const float spectral = (float)(s / spec_count), wave = (float)(wv / wave_count), v = (float)(bce / (double)B);
+    out[0] = wave + spectral + v;
+    out[1] = v;
+    out[2] = wave;
+    out[3] = spectral;
+  }
+}
+
+// out[b] = max |x[b][:]|
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  const float* row = x + (size_t)blockIdx.x * n;
+  float m = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(row[i]));
+  m = wave_reduce_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+}  // namespace
+
+// Per-clip max |x| (train/models.py:614-620) for callers that did not get it from the STFT kernel.
+NOISE_EXPORT int noise_absmax(const float* x, float* out, int B, long n, void* stream) {
+  NOISE_REQUIRE(x && out && B > 0 && n > 0, "noise_absmax: bad argument");
+  hipLaunchKernelGGL(absmax_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  NOISE_CHECK_LAUNCH("noise_absmax");
+  return 0;
+}
+
+NOISE_EXPORT int noise_loss_max_blocks(void) { return 1024; }
+
+// Spectral L1.  partial: at least noise_loss_max_blocks() doubles; *n_partial receives the count written.
+NOISE_EXPORT int noise_spectral_l1(const float* enh, const float* clean_logmag, float* d_enh, double* partial,
+                                   int* n_partial, long n, void* stream) {
+  NOISE_REQUIRE(enh && clean_logmag && partial && n > 0, "noise_spectral_l1: bad argument");
+  const int grid = noise_grid(n, 256 * 8, 1024);
+  if (n_partial) *n_partial = grid;
+  hipLaunchKernelGGL(spectral_l1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enh, clean_logmag, n,
+                     (float)(1.0 / (double)n), d_enh, partial);
+  NOISE_CHECK_LAUNCH("noise_spectral_l1");
+  return 0;
+}
+
+NOISE_EXPORT int noise_vad_label(const float* clean, float* label, int B, int L, int min_active, void* stream) {
+  NOISE_REQUIRE(clean && label && B > 0 && L > 0, "noise_vad_label: bad argument");
+  hipLaunchKernelGGL(vad_label_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, clean, L, min_active, label);
+  NOISE_CHECK_LAUNCH("noise_vad_label");
+  return 0;
+}
+
+// Cross-pair waveform L1 (the reference's broadcast).  partial: ceil(L/16) doubles.
+NOISE_EXPORT int noise_wave_pair_l1(const float* wave, const float* clean, float* d_wave, double* partial, int* n_partial,
+                                    int B, int L, void* stream) {
+  NOISE_REQUIRE(wave && clean && partial && B > 0 && L > 0, "noise_wave_pair_l1: bad argument");
+  const int grid = noise_cdiv(L, WT);
+  if (n_partial) *n_partial = grid;
+  const size_t smem = (size_t)(B < WJ ? B : WJ) * WT * sizeof(float);
+  const double cnt = (double)B * (double)B * (double)L;
+  hipLaunchKernelGGL(wave_pair_l1_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, wave, clean, B, L,
+                     (float)(1.0 / cnt), d_wave, partial);
+  NOISE_CHECK_LAUNCH("noise_wave_pair_l1");
+  return 0;
+}
+
+// out4 = [loss, vad_loss, waveform_loss, spectral_loss]
+NOISE_EXPORT int noise_loss_finalize(const double* spec_partial, int n_spec, long spec_count, const double* wave_partial,
+                                     int n_wave, int B, int L, const float* vad, const float* label, float* d_vad,
+                                     float* out4, void* stream) {
+  NOISE_REQUIRE(spec_partial && wave_partial && vad && label && out4 && B > 0, "noise_loss_finalize: bad argument");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, spec_partial, n_spec,
+                     (double)spec_count, wave_partial, n_wave, (double)B * (double)B * (double)L, vad, label, B, d_vad, out4);
+  NOISE_CHECK_LAUNCH("noise_loss_finalize");
+  return 0;
+}

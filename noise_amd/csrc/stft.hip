@@ -15,7 +15,7 @@
 namespace {
 
 struct StftDims {
-  int B, L, T, n_fft, hop, F, Rpad, Lout;
+  int B, L, T, n_fft, hop, F, Rpad, Lout, accum;
 };
 
 constexpr int STFT_TF = 64;  // frames per workgroup
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(
           } else {
             float sn, cs;
             sincosf(phase[o], &sn, &cs);
-            out0[o] = expf(logmag[o]) * (cs * re + sn * im);
+            const float gv = expf(logmag[o]) * (cs * re + sn * im);
+            out0[o] = d.accum ? out0[o] + gv : gv;
           }
         }
       }
@@ -231,12 +232,15 @@ int launch_frames(const float* sig, const float* basisT, float* out0, float* out
   const size_t smem = (size_t)(nS + nS / d.hop + 1) * sizeof(float);
   dim3 grid(noise_cdiv(d.T, STFT_TF), d.B);
   if (per_wave <= 3) {
+    NOISE_ALLOW_LDS((stft_frames_kernel<MODE, 3>), smem);
     hipLaunchKernelGGL((stft_frames_kernel<MODE, 3>), grid, dim3(256), smem, st, sig, basisT, out0, out1, absmax,
                        wave_out, wsum, logmag, phase, d);
   } else if (per_wave <= 5) {
+    NOISE_ALLOW_LDS((stft_frames_kernel<MODE, 5>), smem);
     hipLaunchKernelGGL((stft_frames_kernel<MODE, 5>), grid, dim3(256), smem, st, sig, basisT, out0, out1, absmax,
                        wave_out, wsum, logmag, phase, d);
   } else {
+    NOISE_ALLOW_LDS((stft_frames_kernel<MODE, 9>), smem);
     hipLaunchKernelGGL((stft_frames_kernel<MODE, 9>), grid, dim3(256), smem, st, sig, basisT, out0, out1, absmax,
                        wave_out, wsum, logmag, phase, d);
   }
@@ -252,7 +256,7 @@ NOISE_EXPORT int noise_stft_fwd(const float* wave, const float* basisT, float* l
   if (check_dims("noise_stft_fwd", B, L, n_fft, hop)) return -1;
   NOISE_REQUIRE(wave && basisT && logmag && phase, "noise_stft_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  StftDims d{B, L, L / hop + 1, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (L / hop)};
+  StftDims d{B, L, L / hop + 1, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (L / hop), 0};
   if (absmax) {
     hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * B, st);
     NOISE_REQUIRE(e == hipSuccess, "noise_stft_fwd: memset failed: %s", hipGetErrorString(e));
@@ -271,7 +275,7 @@ NOISE_EXPORT int noise_istft_fwd(const float* logmag, const float* phase, const 
   hipStream_t st = (hipStream_t)stream;
   const int F = n_fft / 2 + 1, R = n_fft / hop;
   NOISE_REQUIRE(R < ISTFT_TF, "noise_istft_fwd: n_fft/hop=%d too large", R);
-  StftDims d{B, 0, T, n_fft, hop, F, 0, hop * (T - 1)};
+  StftDims d{B, 0, T, n_fft, hop, F, 0, hop * (T - 1), 0};
   NOISE_REQUIRE(d.Lout > 0, "noise_istft_fwd: need at least 2 frames");
   const int TFo = ISTFT_TF - (R - 1);
   const int hops = T - 1 + R;
@@ -279,10 +283,13 @@ NOISE_EXPORT int noise_istft_fwd(const float* logmag, const float* phase, const 
   const size_t smem = (size_t)(2 * F) * 32 * sizeof(float);
   const int per_wave = (n_fft / 32 + 3) / 4;
   if (per_wave <= 3) {
+    NOISE_ALLOW_LDS((istft_kernel<3>), smem);
     hipLaunchKernelGGL((istft_kernel<3>), grid, dim3(256), smem, st, logmag, phase, inv_basis, window_sum, vad_logit, wave_out, d);
   } else if (per_wave <= 4) {
+    NOISE_ALLOW_LDS((istft_kernel<4>), smem);
     hipLaunchKernelGGL((istft_kernel<4>), grid, dim3(256), smem, st, logmag, phase, inv_basis, window_sum, vad_logit, wave_out, d);
   } else {
+    NOISE_ALLOW_LDS((istft_kernel<8>), smem);
     hipLaunchKernelGGL((istft_kernel<8>), grid, dim3(256), smem, st, logmag, phase, inv_basis, window_sum, vad_logit, wave_out, d);
   }
   NOISE_CHECK_LAUNCH("noise_istft_fwd");
@@ -291,16 +298,16 @@ NOISE_EXPORT int noise_istft_fwd(const float* logmag, const float* phase, const 
 
 // Adjoint of noise_istft_fwd w.r.t. the log-magnitude input (the phase receives no gradient:
 // it is taken from the noisy input).  d_wave [B][hop*(T-1)], inv_basisT laid out like the
-// forward basisT ([n_fft][Rpad], row 2f = Re f, row 2f+1 = Im f).
+// forward basisT ([n_fft][Rpad], row 2f = Re f, row 2f+1 = Im f).  accumulate != 0 adds into d_logmag.
 NOISE_EXPORT int noise_istft_bwd(const float* d_wave, const float* wave_out, const float* logmag,
                                  const float* phase, const float* inv_basisT, const float* window_sum,
-                                 float* d_logmag, int B, int T, int n_fft, int hop, void* stream) {
+                                 float* d_logmag, int accumulate, int B, int T, int n_fft, int hop, void* stream) {
   NOISE_REQUIRE(B > 0 && T > 1, "noise_istft_bwd: empty batch (B=%d, T=%d)", B, T);
   if (check_dims("noise_istft_bwd", B, n_fft, n_fft, hop)) return -1;
   NOISE_REQUIRE(d_wave && wave_out && logmag && phase && inv_basisT && window_sum && d_logmag,
                 "noise_istft_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  StftDims d{B, 0, T, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (T - 1)};
+  StftDims d{B, 0, T, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (T - 1), accumulate};
   launch_frames<1>(d_wave, inv_basisT, d_logmag, nullptr, nullptr, wave_out, window_sum, logmag, phase, d, st);
   NOISE_CHECK_LAUNCH("noise_istft_bwd");
   return 0;

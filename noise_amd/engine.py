@@ -1,0 +1,356 @@
+"""Kernel schedule of the denoiser U-Net: forward, backward and the fused training step.
+
+This is the host-side orchestration of the HIP kernels for `Base._forward` / `BaseSpectral._forward`
+/ `_shared_step` of the reference (train/models.py:583-612, :758-764, :766-804).  It owns no
+parameters: it reads them from the module tree built in `noise_amd.models` and writes gradients into
+the tensors its caller designates (views of one flat gradient buffer).
+
+Data layout: every activation is NHWC fp32 and stored RAW (before BatchNorm); consumers apply the
+producer's BatchNorm(+ReLU6) while loading ("lazy" sources), and each conv kernel emits the
+per-channel sums that the BatchNorm of its own output needs, so an activation is written once and
+read once per consumer.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import ptr
+import ctypes
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_U64 = ctypes.c_ulonglong
+_lib.register({
+    "noise_attn_pre_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "noise_attn_core_fwd": [_P, _P, _P, _P, _U64, _F, _L, _I, _I, _I, _I, _P],
+    "noise_attn_core_bwd": [_P, _P, _P, _P, _U64, _F, _P, _L, _I, _I, _I, _I, _P],
+    "noise_attn_post_fwd": [_P] * 22 + [_L, _I, _I, _I, _I, _P],
+    "noise_attn_post_bwd": [_P] * 20 + [_L, _I, _I, _I, _I, _P],
+    "noise_attn_pre_bwd": [_P] * 12 + [_L, _I, _I, _I, _I, _P],
+    "noise_spectral_l1": [_P, _P, _P, _P, _P, _L, _P],
+    "noise_vad_label": [_P, _P, _I, _I, _I, _P],
+    "noise_wave_pair_l1": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "noise_loss_finalize": [_P, _I, _L, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "noise_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P],
+    "noise_absmax": [_P, _P, _I, _L, _P],
+})
+_lib.lib.noise_attn_max_blocks.restype = ctypes.c_int
+_lib.lib.noise_loss_max_blocks.restype = ctypes.c_int
+ATTN_MAX_BLOCKS = _lib.lib.noise_attn_max_blocks()
+LOSS_MAX_BLOCKS = _lib.lib.noise_loss_max_blocks()
+
+ATTN_DROPOUT = 0.1  # ScaledDotProductAttention default, never overridden by the model (models.py:22,55)
+
+
+class _Rec:
+    """One convolution layer of the schedule and the buffers that belong to it."""
+    __slots__ = ("name", "kind", "conv", "bn", "relu6", "C", "Cin", "B", "Hi", "Wi", "Ho", "Wo", "stride",
+                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "g1", "g2", "g_in")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    @property
+    def npix_out(self):
+        return self.B * self.Ho * self.Wo
+
+    @property
+    def npix_in(self):
+        return self.B * self.Hi * self.Wi
+
+    def lazy(self):
+        return (self.y, self.coef, self.relu6)
+
+
+class DenoiserPlan:
+    """Buffers + launch schedule for one (batch, H, W) geometry of one VADMobileNetV2 instance."""
+
+    def __init__(self, net, B, H, W, device):
+        self.net = net
+        self.B, self.H, self.W = B, H, W
+        self.device = device
+        self.hp, self.wp = net.H_padding, net.W_padding
+        f32 = dict(device=device, dtype=torch.float32)
+        self.recs = []
+        enc_blocks = net.block_plan()[0]
+        dec_blocks = net.block_plan()[1]
+
+        def new_rec(name, kind, conv, bn, relu6, Cin, C, Hi, Wi, stride, transposed):
+            Ho = ops.conv_out(Hi, stride[0], transposed)
+            Wo = ops.conv_out(Wi, stride[1], transposed)
+            r = _Rec(name=name, kind=kind, conv=conv, bn=bn, relu6=relu6, C=C, Cin=Cin, B=B, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo,
+                     stride=stride, transposed=transposed)
+            r.y = torch.empty(B, Ho, Wo, C, **f32)
+            r.coef = torch.empty(4 * C, **f32)
+            r.coef3 = torch.empty(3 * C, **f32)
+            self.recs.append(r)
+            return r
+
+        # ---- encoder
+        self.enc = []       # list of lists of recs per block
+        Hc, Wc = H + self.hp, W + self.wp
+        blk = enc_blocks[0]
+        m = net.encoder[0]
+        r = new_rec("encoder.0", "first", m[0], m[1], True, 1, blk["cout"], Hc, Wc, blk["stride"], False)
+        self.enc.append([r])
+        for i, blk in enumerate(enc_blocks[1:], start=1):
+            seq = net.encoder[i].conv
+            layers = []
+            idx = 0
+            cur = self.enc[-1][-1]
+            if blk["t"] != 1:
+                layers.append(new_rec(f"encoder.{i}.pw", "pw", seq[0][0], seq[0][1], True, blk["cin"], blk["hidden"],
+                                      cur.Ho, cur.Wo, (1, 1), False))
+                idx = 1
+                cur = layers[-1]
+            layers.append(new_rec(f"encoder.{i}.dw", "dw", seq[idx][0], seq[idx][1], True, blk["hidden"], blk["hidden"],
+                                  cur.Ho, cur.Wo, blk["stride"], False))
+            cur = layers[-1]
+            layers.append(new_rec(f"encoder.{i}.lin", "pw", seq[idx + 1], seq[idx + 2], False, blk["hidden"], blk["cout"],
+                                  cur.Ho, cur.Wo, (1, 1), False))
+            self.enc.append(layers)
+        bott = self.enc[-1][-1]
+        self.n_tok = bott.Ho * bott.Wo
+        self.d_model = bott.C
+        self.ntok = B * self.n_tok
+        # ---- attention buffers
+        hd = net.n_head * net.d_k
+        self.hd = hd
+        nt, D = self.ntok, self.d_model
+        self.xhat0 = torch.empty(nt, D, **f32)
+        self.rstd0 = torch.empty(nt, **f32)
+        self.qkv = torch.empty(nt, 3 * hd, **f32)
+        self.att_o = torch.empty(nt, hd, **f32)
+        self.ml = torch.empty(B * net.n_head * self.n_tok * 2, **f32)
+        self.xhat1 = torch.empty(nt, D, **f32)
+        self.rstd1 = torch.empty(nt, **f32)
+        self.hdn = torch.empty(nt, D, **f32)
+        self.xhat2 = torch.empty(nt, D, **f32)
+        self.rstd2 = torch.empty(nt, **f32)
+        self.x3 = torch.empty(nt, D, **f32)
+        self.vad = torch.empty(B, **f32)
+        # ---- decoder
+        self.dec = []
+        Hc, Wc = bott.Ho, bott.Wo
+        for i, blk in enumerate(dec_blocks):
+            skip = self.enc[len(self.enc) - 1 - i][-1]
+            if (skip.Ho, skip.Wo) != (Hc, Wc):
+                raise NotImplementedError(
+                    f"decoder block {i}: skip {skip.Ho}x{skip.Wo} vs input {Hc}x{Wc}; only padded geometries whose "
+                    "skip crops are empty are supported (pad with the searched H/W_padding)")
+            if blk["kind"] == "last":
+                m = net.decoder[i]
+                r = _Rec(name=f"decoder.{i}", kind="last", conv=m[0], bn=None, relu6=False, C=1, Cin=blk["cin"], B=B, Hi=Hc,
+                         Wi=Wc, Ho=H, Wo=W, stride=blk["stride"], transposed=True)
+                full_h, full_w = ops.conv_out(Hc, blk["stride"][0], True), ops.conv_out(Wc, blk["stride"][1], True)
+                if full_h < H or full_w < W:
+                    raise RuntimeError(f"U-Net output {full_h}x{full_w} is smaller than its input {H}x{W}: "
+                                       "H_padding/W_padding do not fit this input size")
+                self.recs.append(r)
+                self.dec.append([r])
+                continue
+            seq = net.decoder[i].conv
+            layers = []
+            idx = 0
+            if blk["t"] != 1:
+                layers.append(new_rec(f"decoder.{i}.pw", "pw", seq[0][0], seq[0][1], True, blk["cin"], blk["hidden"], Hc, Wc,
+                                      (1, 1), False))
+                idx = 1
+            layers.append(new_rec(f"decoder.{i}.dw", "dw", seq[idx][0], seq[idx][1], True, blk["hidden"], blk["hidden"], Hc,
+                                  Wc, blk["stride"], True))
+            cur = layers[-1]
+            layers.append(new_rec(f"decoder.{i}.lin", "pw", seq[idx + 1], seq[idx + 2], False, blk["hidden"], blk["cout"],
+                                  cur.Ho, cur.Wo, (1, 1), False))
+            self.dec.append(layers)
+            Hc, Wc = cur.Ho, cur.Wo
+        self.enh = torch.empty(B, H, W, **f32)
+        # ---- scratch shared by all layers
+        maxC = max(r.C for r in self.recs)
+        maxw = max((r.C * r.Cin for r in self.recs if r.kind == "pw"), default=1)
+        att_cols = max(2 * D * D + D * hd + 7 * D + 1, 3 * hd * D + 2 * D)
+        self.slab = torch.empty(max(ops.CONV_MAX_BLOCKS * 10 * maxC, ops.PW_WGRAD_MAX_BLOCKS * maxw,
+                                    ATTN_MAX_BLOCKS * att_cols), **f32)
+        self.att_grads = torch.empty(att_cols, **f32)
+        self.bwd_ready = False
+
+    # -------------------------------------------------------------------------------- backward buffers
+    def ensure_backward_buffers(self):
+        if self.bwd_ready:
+            return
+        f32 = dict(device=self.device, dtype=torch.float32)
+        for r in self.recs:
+            if r.kind != "first":
+                r.g_in = torch.empty(r.B, r.Hi, r.Wi, r.Cin, **f32)
+        nt, D, hd = self.ntok, self.d_model, self.hd
+        self.d_o = torch.empty(nt, hd, **f32)
+        self.d_x1 = torch.empty(nt, D, **f32)
+        self.d_qkv = torch.empty(nt, 3 * hd, **f32)
+        self.d_x0 = torch.empty(nt, D, **f32)
+        self.bwd_ready = True
+
+    # -------------------------------------------------------------------------------- forward
+    def _bn(self, r, rows, training):
+        bn = r.bn
+        if training:
+            ops.bn_finalize_fwd(self.slab, rows, r.C, r.npix_out, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, r.coef, momentum=bn.momentum, eps=bn.eps)
+        else:
+            ops.bn_coef_eval(r.C, bn.weight, bn.bias, bn.running_mean, bn.running_var, r.coef, eps=bn.eps)
+
+    def _run_layer(self, r, a, b, training):
+        slab = self.slab if training else None
+        r.src_a, r.src_b = a, b
+        if r.kind == "pw":
+            rows = ops.pw_fwd(a, b, r.conv.weight, r.y, slab, r.npix_in, r.Cin, r.C)
+        else:
+            rows = ops.dw3x3_fwd(a, b, r.conv.weight, r.y, slab, r.transposed, r.B, r.Hi, r.Wi, r.C, r.stride)
+        self._bn(r, rows, training)
+
+    def forward(self, logmag, absmax, training, keep=None, seed=0):
+        """logmag (B,H,W) raw log-magnitudes, absmax (B,) -> enhanced log-magnitudes (B,H,W), vad (B,)."""
+        net = self.net
+        self.logmag, self.absmax = logmag, absmax
+        self.keep, self.seed = keep, int(seed)
+        self.p_drop = ATTN_DROPOUT if training else 0.0
+        r0 = self.enc[0][0]
+        rows = ops.first_conv_fwd(logmag, absmax, r0.conv.weight, r0.y, self.slab if training else None, self.B, self.H,
+                                  self.W, self.hp, self.wp, net.pad_value, r0.C, r0.stride)
+        self._bn(r0, rows, training)
+        cur = r0.lazy()
+        for layers in self.enc[1:]:
+            for r in layers:
+                self._run_layer(r, cur, None, training)
+                cur = r.lazy()
+        bott = cur
+        # ---- attention block
+        att = net.bottleneck_attention
+        ly = att.layer_stack[0]
+        sa, ff = ly.slf_attn, ly.pos_ffn
+        st = _lib.stream()
+        dims = (self.ntok, self.n_tok, self.d_model, net.n_head, net.d_k)
+        _lib.call("noise_attn_pre_fwd", ptr(bott[0]), ptr(bott[1]), int(bott[2]), ptr(att.layer_norm.weight),
+                  ptr(att.layer_norm.bias), ptr(sa.w_qs.weight), ptr(sa.w_ks.weight), ptr(sa.w_vs.weight), ptr(self.xhat0),
+                  ptr(self.rstd0), ptr(self.qkv), *dims, st)
+        _lib.call("noise_attn_core_fwd", ptr(self.qkv), ptr(self.att_o), ptr(self.ml), ptr(keep), self.seed,
+                  float(self.p_drop if keep is None else ATTN_DROPOUT), *dims, st)
+        _lib.call("noise_attn_post_fwd", ptr(self.att_o), ptr(self.xhat0), ptr(att.layer_norm.weight),
+                  ptr(att.layer_norm.bias), ptr(sa.fc.weight), ptr(sa.layer_norm.weight), ptr(sa.layer_norm.bias),
+                  ptr(ff.w_1.weight), ptr(ff.w_1.bias), ptr(ff.w_2.weight), ptr(ff.w_2.bias), ptr(ff.layer_norm.weight),
+                  ptr(ff.layer_norm.bias), ptr(net.vad.weight), ptr(net.vad.bias), ptr(self.xhat1), ptr(self.rstd1),
+                  ptr(self.hdn), ptr(self.xhat2), ptr(self.rstd2), ptr(self.x3), ptr(self.vad), *dims, st)
+        # ---- decoder
+        cur = (self.x3, None, False)
+        for i, layers in enumerate(self.dec):
+            skip = self.enc[len(self.enc) - 1 - i][-1].lazy()
+            first = True
+            for r in layers:
+                if r.kind == "last":
+                    r.src_a, r.src_b = cur, skip
+                    ops.last_convT_fwd(cur, skip, r.conv.weight, r.conv.bias, logmag, absmax, self.enh, None, r.B, r.Hi,
+                                       r.Wi, r.Cin, r.stride, self.H, self.W)
+                else:
+                    self._run_layer(r, cur, skip if first else None, training)
+                    cur = r.lazy()
+                first = False
+        return self.enh, self.vad
+
+    # -------------------------------------------------------------------------------- backward
+    def backward(self, d_enh, d_vad, grad_of):
+        """d_enh (B,H,W) = dL/d(enhanced log-magnitude), d_vad (B,) = dL/d(vad logit).
+        `grad_of(param)` returns the tensor that receives that parameter's gradient (overwritten)."""
+        self.ensure_backward_buffers()
+        net = self.net
+        G = grad_of
+        for r in self.recs:
+            r.g1 = r.g2 = None
+        by_y = {id(r.y): r for r in self.recs if r.y is not None}
+
+        def route(src, g):
+            """register g as a gradient of the producer of lazy source `src`"""
+            if src is None:
+                return
+            prod = by_y.get(id(src[0]))
+            if prod is None:
+                return
+            if prod.g1 is None:
+                prod.g1 = g
+            else:
+                prod.g2 = g
+
+        def bn_backward(r):
+            need_write = r.relu6 or r.g2 is not None
+            # a gradient buffer that is also someone's second gradient must stay intact: write in place only into g1
+            ops.bn_bwd(r.g1, r.g2, r.y, r.coef, r.relu6, r.bn.weight, r.g1 if need_write else None, G(r.bn.weight),
+                       G(r.bn.bias), r.coef3, self.slab, r.npix_out, r.C)
+            return (r.g1, r.y, r.coef3)
+
+        # ---- last layer
+        last = self.dec[-1][0]
+        ops.last_convT_bwd(d_enh, self.enh, self.absmax, last.src_a, last.src_b, last.conv.weight, last.g_in,
+                           G(last.conv.weight), G(last.conv.bias), self.slab, last.B, last.Hi, last.Wi, last.Cin,
+                           last.stride, self.H, self.W)
+        # order matters: the skip (second) gradient of an encoder tensor is registered first as g1 only if no main
+        # consumer exists yet; main consumers of encoder tensors run later, so route skip grads into g2 explicitly.
+        route_main = route
+
+        def route_skip(src, g):
+            prod = by_y.get(id(src[0])) if src is not None else None
+            if prod is not None:
+                prod.g2 = g
+
+        route_main(last.src_a, last.g_in)
+        route_skip(last.src_b, last.g_in)
+
+        def layer_backward(r):
+            grad = bn_backward(r)
+            if r.kind == "pw":
+                ops.pw_wgrad(grad, r.src_a, r.src_b, G(r.conv.weight), self.slab, r.npix_in, r.C, r.Cin)
+                ops.pw_dgrad(grad, r.conv.weight, None, r.g_in, r.npix_in, r.C, r.Cin)
+            else:
+                ops.dw3x3_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, G(r.conv.weight), self.slab, r.transposed,
+                              r.B, r.Hi, r.Wi, r.C, r.stride)
+            route_main(r.src_a, r.g_in)
+            route_skip(r.src_b, r.g_in)
+
+        for layers in reversed(self.dec[:-1]):
+            for r in reversed(layers):
+                layer_backward(r)
+        # ---- attention block: dL/dx3 is the input gradient of the first decoder layer
+        g3 = self.dec[0][0].g_in
+        att = net.bottleneck_attention
+        ly = att.layer_stack[0]
+        sa, ff = ly.slf_attn, ly.pos_ffn
+        st = _lib.stream()
+        dims = (self.ntok, self.n_tok, self.d_model, net.n_head, net.d_k)
+        D, hd = self.d_model, self.hd
+        _lib.call("noise_attn_post_bwd", ptr(g3), ptr(d_vad), ptr(self.att_o), ptr(self.xhat1), ptr(self.rstd1),
+                  ptr(self.hdn), ptr(self.xhat2), ptr(self.rstd2), ptr(self.x3), ptr(sa.fc.weight),
+                  ptr(sa.layer_norm.weight), ptr(sa.layer_norm.bias), ptr(ff.w_1.weight), ptr(ff.w_2.weight),
+                  ptr(ff.layer_norm.weight), ptr(net.vad.weight), ptr(self.d_o), ptr(self.d_x1), ptr(self.att_grads),
+                  ptr(self.slab), *dims, st)
+        g = self.att_grads
+        o = 0
+        for t, n in ((ff.w_2.weight, D * D), (ff.w_1.weight, D * D), (sa.fc.weight, D * hd), (ff.layer_norm.weight, D),
+                     (ff.layer_norm.bias, D), (ff.w_2.bias, D), (ff.w_1.bias, D), (sa.layer_norm.weight, D),
+                     (sa.layer_norm.bias, D), (net.vad.weight, D), (net.vad.bias, 1)):
+            G(t).view(-1).copy_(g[o:o + n])
+            o += n
+        _lib.call("noise_attn_core_bwd", ptr(self.qkv), ptr(self.d_o), ptr(self.ml), ptr(self.keep), self.seed,
+                  float(self.p_drop if self.keep is None else ATTN_DROPOUT), ptr(self.d_qkv), *dims, st)
+        _lib.call("noise_attn_pre_bwd", ptr(self.d_qkv), ptr(self.d_x1), ptr(self.xhat0), ptr(self.rstd0),
+                  ptr(att.layer_norm.weight), ptr(att.layer_norm.bias), ptr(sa.w_qs.weight), ptr(sa.w_ks.weight),
+                  ptr(sa.w_vs.weight), ptr(self.d_x0), ptr(self.att_grads), ptr(self.slab), *dims, st)
+        o = 0
+        for t, n in ((sa.w_qs.weight, hd * D), (sa.w_ks.weight, hd * D), (sa.w_vs.weight, hd * D),
+                     (att.layer_norm.weight, D), (att.layer_norm.bias, D)):
+            G(t).view(-1).copy_(g[o:o + n])
+            o += n
+        bott = self.enc[-1][-1]
+        bott.g1 = self.d_x0.view(bott.B, bott.Ho, bott.Wo, bott.C)   # (its g2 is the skip gradient from decoder.0)
+        # ---- encoder
+        for layers in reversed(self.enc[1:]):
+            for r in reversed(layers):
+                layer_backward(r)
+        r0 = self.enc[0][0]
+        grad = bn_backward(r0)
+        ops.first_conv_wgrad(grad, self.logmag, self.absmax, G(r0.conv.weight), self.slab, self.B, self.H, self.W, self.hp,
+                             self.wp, net.pad_value, r0.C, r0.stride)

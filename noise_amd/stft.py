@@ -136,14 +136,15 @@ class STFT(torch.nn.Module):
                   self.hop_length, _lib.stream())
         return out
 
-    def _inverse_bwd(self, grad_out, out, log_magnitude, phase):
+    def _inverse_bwd(self, grad_out, out, log_magnitude, phase, d_lm=None, accumulate=False):
         B, _, F, T = log_magnitude.shape
         _, inv_basisT = self._bases()
         g = grad_out.contiguous().float()
-        d_lm = torch.empty_like(log_magnitude, dtype=torch.float32)
+        if d_lm is None:
+            d_lm = torch.empty_like(log_magnitude, dtype=torch.float32)
         _lib.call("noise_istft_bwd", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
                   _lib.ptr(phase.contiguous()), _lib.ptr(inv_basisT), _lib.ptr(self.window_sum), _lib.ptr(d_lm),
-                  B, T, self.n_fft, self.hop_length, _lib.stream())
+                  int(accumulate), B, T, self.n_fft, self.hop_length, _lib.stream())
         return d_lm
 
     def inverse(self, log_magnitude, phase):
