@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds per second of the full training step
+(STFT x2 -> denoiser fwd -> iSTFT -> losses -> backward -> gradient all-reduce -> AdamW) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a batch of 64
+synthetic 16 kHz clips of 10 s, which the training step views as 1280 segments of 8000 samples
+(train/models.py:768-769), reference STFT configuration n_fft 320 / hop 160, fp32.  Weak scaling: every
+rank processes its own 640 audio-seconds per step; the only exchange is one all-reduce of the 76,146-float
+gradient buffer.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LAYER_CONFIG = [[1, 32, 1, [3, 3], [2, 2]], [1, 16, 1, [3, 3], [1, 1]], [3, 24, 1, [3, 3], [2, 2]],
+                [3, 32, 1, [3, 3], [2, 2]], [3, 64, 1, [3, 3], [2, 2]]]
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def build_model(device):
+    from noise_amd import VADSpectralV2
+    torch.manual_seed(0)
+    m = VADSpectralV2(n_fft=320, hop_length=160, win_length=320, window="hann", nhead=6, num_layers=1, dropout=0.0,
+                      layer_config=[list(r) for r in LAYER_CONFIG], pad_value=-1, max_frames=1200)
+    return m.to(device).train()
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (a port of the reference algorithm) on a bounded sample of the same workload:
+    training steps of 128 segments (64 audio-seconds) on the host cores."""
+    from oracle import spectral as osp
+    from noise_amd.data import synth_batch
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = build_model("cpu")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and
+              not ("running" in k or k.startswith("stft."))}
+    sd.update(params)
+    bufs = osp.stft_buffers(1200, 320, 160)
+    B = 128
+    noisy, clean, _ = synth_batch(B, 8000, "cpu", seed=1234)
+    mom = {k: torch.zeros_like(p) for k, p in params.items()}
+    var = {k: torch.zeros_like(p) for k, p in params.items()}
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        keep = torch.rand(B, 6, 55, 55) > 0.1
+        loss, _ = osp.shared_step(noisy, clean, sd, bufs, 320, 160, training=True, new_stats={}, attn_keep=keep)
+        loss.backward()
+        with torch.no_grad():
+            for k, p in params.items():
+                osp.adamw_step(p, p.grad, mom[k], var[k], steps + 1)
+                p.grad = None
+        steps += 1
+        el = time.perf_counter() - t0
+        if steps >= 2 and (el > seconds_budget or steps >= 20):
+            break
+    # first step is warm-up-ish on CPU as well; report the steady average over all timed steps
+    return {"value": round(steps * B * 0.5 / el, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "sample": f"{steps} training steps of {B} x 0.5 s segments (fwd+bwd+AdamW, fp32) on the CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=64, help="10 s clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-entry-point table to stderr")
+    args = ap.parse_args()
+
+    from noise_amd import _lib, dist as ndist
+    from noise_amd.data import synth_batch
+    rank, world, local_rank = ndist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    model = build_model(device)
+    opt = model.configure_optimizers()
+    all_reduce = ndist.make_grad_all_reduce()
+    clip_len = 160000
+    noisy, clean, _ = synth_batch(args.clips, clip_len, device, seed=1234 + rank)
+    audio_s_per_step = args.clips * clip_len / 16000.0
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step_fused(noisy, clean, opt, all_reduce)
+    barrier()
+    _lib.PROFILE = prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out4 = model.train_step_fused(noisy, clean, opt, all_reduce)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.PROFILE = None
+    loss = float(out4[0].item())
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- per-entry-point HIP-event timing (rank 0): algorithmic bytes / measured time
+    fam = {}
+    for name, nbytes, e0, e1 in prof:
+        f = fam.setdefault(name, [0.0, 0, 0])
+        f[0] += e0.elapsed_time(e1)
+        f[1] += nbytes
+        f[2] += 1
+    total_ms = sum(v[0] for v in fam.values())
+    rows = sorted(fam.items(), key=lambda kv: -kv[1][0])
+    if args.breakdown and rank == 0:
+        for name, (ms, nb, n) in rows:
+            print(f"{name:28s} {ms / args.steps:9.3f} ms/step {100 * ms / total_ms:5.1f}%  {n // args.steps:4d} calls  "
+                  f"{nb / 1e6 / max(ms, 1e-9):9.1f} GB/s", file=sys.stderr)
+    dom, (dms, dbytes, dn) = rows[0]
+    achieved = dbytes / 1e6 / dms  # bytes / ms -> GB/s
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches_per_step": dn // args.steps, "avg_launch_ms": round(dms / dn, 4),
+                "share_of_step": round(dms / total_ms, 3),
+                "step_hbm_frac": round(sum(v[1] for v in fam.values()) / 1e6 / total_ms / HBM_PEAK_GBS, 4)}
+
+    if rank == 0:
+        line = {
+            "metric": "audio-sec/sec", "value": round(world * audio_s_per_step * args.steps / elapsed, 1),
+            "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train_step fwd+bwd+AdamW, 64 x 10 s clips/GPU = 1280 x 0.5 s segments, n_fft 320 hop 160",
+                       "global_batch_clips": world * args.clips, "segments_per_gpu": args.clips * clip_len // 8000,
+                       "parallelism": f"dp{world}", "loss": round(loss, 5)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/* noise_hip.h - C ABI of libnoise_hip.so: MI355X (gfx950) kernels for the speech-enhancement hot path.
+ *
+ * The reference (vinhng10/noise) has no native boundary: its hot path is a sequence of ATen ops
+ * called from Python.  Each entry point below replaces the ATen op sequence at the cited reference
+ * lines (paths relative to the reference root).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (plain pointers and sizes only);
+ *     the library never allocates, frees or retains memory; `scratch` arguments are caller-owned
+ *     workspaces whose minimum sizes are stated per function;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success; otherwise nothing was launched and noise_last_error() describes why;
+ *   - activations are NHWC fp32; spectra are [B][F][T] fp32; waveforms [B][L] fp32;
+ *   - "lazy source" (y, coef, relu6): a = act(coef[c]*y + coef[C+c]) with coef = [scale|shift|mean|invstd]
+ *     (coef may be NULL: a = y);  "lazy gradient" (dz, y, coef3): dy = coef3[c]*dz + coef3[C+c]*y + coef3[2C+c]
+ *     (coef3 may be NULL: dy = dz).
+ */
+#ifndef NOISE_HIP_H
+#define NOISE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------- */
+const char* noise_last_error(void);   /* text of the last failure on the calling thread */
+int noise_version(void);
+
+/* ---- STFT / iSTFT: train/models.py:460-475 (STFT.forward), :477-495 (STFT.inverse) ---------- */
+int noise_stft_rpad(int n_fft);       /* row count of the interleaved, transposed basis layout */
+/* wave [B][L] -> logmag, phase [B][F][T], T = L/hop + 1; absmax [B] (optional) = max |logmag| per clip
+ * (models.py:614-620).  basisT [n_fft][rpad]: column 2f = Re row f, 2f+1 = Im row f of forward_basis. */
+int noise_stft_fwd(const float* wave, const float* basisT, float* logmag, float* phase, float* absmax,
+                   int B, int L, int n_fft, int hop, void* stream);
+/* logmag, phase [B][F][T] -> wave_out [B][hop*(T-1)], clamped to [-1,1]; inv_basis [2F][n_fft] and
+ * window_sum as registered by the reference module; vad_logit [B] (optional) applies the inference
+ * gate wave *= sigmoid(1e4*vad) (models.py:754). */
+int noise_istft_fwd(const float* logmag, const float* phase, const float* inv_basis, const float* window_sum,
+                    const float* vad_logit, float* wave_out, int B, int T, int n_fft, int hop, void* stream);
+/* autograd of models.py:477-495 w.r.t. log_magnitude; inv_basisT in the noise_stft_fwd basis layout */
+int noise_istft_bwd(const float* d_wave, const float* wave_out, const float* logmag, const float* phase,
+                    const float* inv_basisT, const float* window_sum, float* d_logmag, int accumulate,
+                    int B, int T, int n_fft, int hop, void* stream);
+
+/* ---- SNR mixer: process/audiolib.py:176-216 (+ :219-248, :30-35, :18-19), :251-289 ---------- */
+/* clean, noise [U][L] float64 (already length-matched); snr, level_draw [U]; outputs [U][L], level_out [U] */
+int noise_snr_mix(const double* clean, const double* noise, const int* snr, const int* level_draw,
+                  double* clean_out, double* noise_out, double* noisy_out, int* level_out,
+                  int n_utt, long L, double target_level, double clipping_threshold, void* stream);
+int noise_activity(const double* audio, double* perc_active, int n_utt, long L, int fs,
+                   double energy_thresh, double target_level, void* stream);
+
+/* ---- U-Net layers: train/models.py:583-612 (Base._forward), :348-407, :299-345, :1151-1201 -- */
+int noise_conv_max_blocks(void);      /* slab rows a conv/bn kernel may write (sizes the scratch buffers) */
+/* depthwise 3x3, pad 1 (Conv2d :385-393 or ConvTranspose2d :299-345), input = lazy a (+ lazy b);
+ * out raw [B][Ho][Wo][C]; stats_slab (optional) receives *slab_rows rows of [sum(C)|sumsq(C)] */
+int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
+                    int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, int transposed,
+                    int B, int Hi, int Wi, int C, int sy, int sx, void* stream);
+/* g_in [B][Hi][Wi][C], dw (C,1,3,3); scratch >= noise_conv_max_blocks()*9*C floats */
+int noise_dw3x3_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,
+                    int a_relu6, const float* b_y, const float* b_coef, int b_relu6, const float* w, float* g_in,
+                    float* dw, float* scratch, int transposed, int B, int Hi, int Wi, int C, int sy, int sx,
+                    void* stream);
+/* first Conv2d 1->C (models.py:1151-1159) fused with normalise (:614-622) and left/top pad (:589) */
+int noise_first_conv_fwd(const float* logmag, const float* absmax, const float* w, float* out, float* stats_slab,
+                         int* slab_rows, int B, int H, int W, int hp, int wp, float pad_value, int C, int sy,
+                         int sx, void* stream);
+int noise_first_conv_wgrad(const float* dz, const float* y_out, const float* coef3, const float* logmag,
+                           const float* absmax, float* dw, float* scratch, int B, int H, int W, int hp, int wp,
+                           float pad_value, int C, int sy, int sx, void* stream);
+/* last ConvTranspose2d C->1 with bias (models.py:1164-1171) fused with crop (:610) and the additive mask
+ * enh = clamp(logmag/max + filt, -1, 1)*max (:762-763); either of enh / filt may be NULL */
+int noise_last_convT_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
+                         int b_relu6, const float* w, const float* bias, const float* logmag, const float* absmax,
+                         float* enh, float* filt, int B, int Hi, int Wi, int C, int sy, int sx, int H, int W,
+                         void* stream);
+/* scratch >= noise_conv_max_blocks()*10*C floats */
+int noise_last_convT_bwd(const float* d_enh, const float* enh, const float* absmax, const float* a_y,
+                         const float* a_coef, int a_relu6, const float* b_y, const float* b_coef, int b_relu6,
+                         const float* w, float* g_in, float* dw, float* dbias, float* scratch, int B, int Hi, int Wi,
+                         int C, int sy, int sx, int H, int W, void* stream);
+/* pointwise convs (models.py:371-381, :395-396) as fp32 MFMA products: out [npix][N] = a [npix][K] x W[N][K]^T */
+int noise_pw_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
+                 int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, long npix, int K, int N,
+                 void* stream);
+int noise_pw_dgrad(const float* dz, const float* y_out, const float* coef3, const float* w, const float* add,
+                   float* g_in, long npix, int Cout, int Cin, void* stream);
+int noise_pw_wgrad_max_blocks(void);
+/* scratch >= noise_pw_wgrad_max_blocks()*Cout*Cin floats */
+int noise_pw_wgrad(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,
+                   int a_relu6, const float* b_y, const float* b_coef, int b_relu6, float* dw, float* scratch,
+                   long npix, int Cout, int Cin, void* stream);
+
+/* ---- BatchNorm2d in train / eval mode (every norm_layer of models.py:371-397, :1151-1159) ---- */
+int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, long count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                          float eps, float* coef, void* stream);
+int noise_bn_coef_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* coef, void* stream);
+/* dz may alias g1; scratch >= noise_conv_max_blocks()*2*C floats */
+int noise_bn_bwd(const float* g1, const float* g2, const float* y, const float* coef, int relu6, const float* gamma,
+                 float* dz, float* dgamma, float* dbeta, float* coef3, float* scratch, long npix, int C, void* stream);
+
+/* ---- bottleneck attention block: models.py:207-225, :60-89, :27-37, :102-112, vad head :602 --- */
+int noise_attn_max_blocks(void);
+int noise_attn_pre_fwd(const float* x_y, const float* x_coef, int x_relu6, const float* ln_w, const float* ln_b,
+                       const float* wq, const float* wk, const float* wv, float* xhat0, float* rstd0, float* qkv,
+                       long ntok, int n, int d_model, int heads, int dk, void* stream);
+/* keep: optional uint8 [B][heads][n][n] keep-mask of the attention dropout (models.py:34); otherwise a
+ * counter-based RNG keyed on (seed, element index) with drop probability p_drop */
+int noise_attn_core_fwd(const float* qkv, float* o, float* ml, const unsigned char* keep, unsigned long long seed,
+                        float p_drop, long ntok, int n, int d_model, int heads, int dk, void* stream);
+int noise_attn_core_bwd(const float* qkv, const float* d_o, const float* ml, const unsigned char* keep,
+                        unsigned long long seed, float p_drop, float* d_qkv, long ntok, int n, int d_model,
+                        int heads, int dk, void* stream);
+int noise_attn_post_fwd(const float* o, const float* xhat0, const float* ln0_w, const float* ln0_b, const float* fc,
+                        const float* ln1_w, const float* ln1_b, const float* w1, const float* b1, const float* w2,
+                        const float* b2, const float* ln2_w, const float* ln2_b, const float* vad_w,
+                        const float* vad_b, float* xhat1, float* rstd1, float* hdn, float* xhat2, float* rstd2,
+                        float* x3, float* vad, long ntok, int n, int d_model, int heads, int dk, void* stream);
+/* grads = [dW2|dW1|dWfc|dln2_w|dln2_b|db2|db1|dln1_w|dln1_b|dvad_w|dvad_b]; scratch: noise_attn_max_blocks() rows */
+int noise_attn_post_bwd(const float* g3, const float* d_vad, const float* o, const float* xhat1, const float* rstd1,
+                        const float* hdn, const float* xhat2, const float* rstd2, const float* x3, const float* fc,
+                        const float* ln1_w, const float* ln1_b, const float* w1, const float* w2, const float* ln2_w,
+                        const float* vad_w, float* d_o, float* d_x1, float* grads, float* scratch, long ntok, int n,
+                        int d_model, int heads, int dk, void* stream);
+/* grads = [dWq|dWk|dWv|dln0_w|dln0_b] */
+int noise_attn_pre_bwd(const float* d_qkv, const float* d_x1, const float* xhat0, const float* rstd0,
+                       const float* ln_w, const float* ln_b, const float* wq, const float* wk, const float* wv,
+                       float* d_x0, float* grads, float* scratch, long ntok, int n, int d_model, int heads, int dk,
+                       void* stream);
+
+/* ---- losses of BaseSpectral._shared_step: models.py:776-790 ---------------------------------- */
+int noise_absmax(const float* x, float* out, int B, long n, void* stream);          /* models.py:614-620 */
+int noise_loss_max_blocks(void);
+int noise_spectral_l1(const float* enh, const float* clean_logmag, float* d_enh, double* partial, int* n_partial,
+                      long n, void* stream);                                          /* :777 */
+int noise_vad_label(const float* clean, float* label, int B, int L, int min_active, void* stream);   /* :782 */
+/* l1_loss((B,1,1,L),(B,L)) broadcasts to all (i,j) clip pairs (:786-787); partial: ceil(L/16) doubles */
+int noise_wave_pair_l1(const float* wave, const float* clean, float* d_wave, double* partial, int* n_partial,
+                       int B, int L, void* stream);
+/* out4 = [loss, vad_loss, waveform_loss, spectral_loss] (:790-797); d_vad = dBCE/dlogit (:780-783) */
+int noise_loss_finalize(const double* spec_partial, int n_spec, long spec_count, const double* wave_partial,
+                        int n_wave, int B, int L, const float* vad, const float* label, float* d_vad, float* out4,
+                        void* stream);
+
+/* ---- optimizer: torch.optim.AdamW as configured by train/main.py:13-14, spectralv2.yaml:99-111 */
+int noise_adamw_step(float* p, const float* g, float* m, float* v, long long* step, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOISE_HIP_H */

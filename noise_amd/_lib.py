@@ -64,10 +64,23 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def call(name, *args):
+# When PROFILE is a list, every entry-point call is bracketed by HIP events on the current stream and
+# (name, algorithmic_bytes, start_event, end_event) is appended: bench.py turns that into per-kernel GB/s.
+PROFILE = None
+
+
+def call(name, *args, nbytes=0):
+    prof = PROFILE
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.noise_last_error().decode()}")
+    if prof is not None:
+        ev1.record()
+        prof.append((name, nbytes, ev0, ev1))
 
 
 def require_cuda(*tensors):

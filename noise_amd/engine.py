@@ -229,14 +229,15 @@ class DenoiserPlan:
         dims = (self.ntok, self.n_tok, self.d_model, net.n_head, net.d_k)
         _lib.call("noise_attn_pre_fwd", ptr(bott[0]), ptr(bott[1]), int(bott[2]), ptr(att.layer_norm.weight),
                   ptr(att.layer_norm.bias), ptr(sa.w_qs.weight), ptr(sa.w_ks.weight), ptr(sa.w_vs.weight), ptr(self.xhat0),
-                  ptr(self.rstd0), ptr(self.qkv), *dims, st)
+                  ptr(self.rstd0), ptr(self.qkv), *dims, st, nbytes=4 * self.ntok * (2 * self.d_model + 3 * self.hd))
         _lib.call("noise_attn_core_fwd", ptr(self.qkv), ptr(self.att_o), ptr(self.ml), ptr(keep), self.seed,
-                  float(self.p_drop if keep is None else ATTN_DROPOUT), *dims, st)
+                  float(self.p_drop if keep is None else ATTN_DROPOUT), *dims, st, nbytes=4 * self.ntok * 4 * self.hd)
         _lib.call("noise_attn_post_fwd", ptr(self.att_o), ptr(self.xhat0), ptr(att.layer_norm.weight),
                   ptr(att.layer_norm.bias), ptr(sa.fc.weight), ptr(sa.layer_norm.weight), ptr(sa.layer_norm.bias),
                   ptr(ff.w_1.weight), ptr(ff.w_1.bias), ptr(ff.w_2.weight), ptr(ff.w_2.bias), ptr(ff.layer_norm.weight),
                   ptr(ff.layer_norm.bias), ptr(net.vad.weight), ptr(net.vad.bias), ptr(self.xhat1), ptr(self.rstd1),
-                  ptr(self.hdn), ptr(self.xhat2), ptr(self.rstd2), ptr(self.x3), ptr(self.vad), *dims, st)
+                  ptr(self.hdn), ptr(self.xhat2), ptr(self.rstd2), ptr(self.x3), ptr(self.vad), *dims, st,
+                  nbytes=4 * self.ntok * (self.hd + 5 * self.d_model))
         # ---- decoder
         cur = (self.x3, None, False)
         for i, layers in enumerate(self.dec):
@@ -326,7 +327,7 @@ class DenoiserPlan:
                   ptr(self.hdn), ptr(self.xhat2), ptr(self.rstd2), ptr(self.x3), ptr(sa.fc.weight),
                   ptr(sa.layer_norm.weight), ptr(sa.layer_norm.bias), ptr(ff.w_1.weight), ptr(ff.w_2.weight),
                   ptr(ff.layer_norm.weight), ptr(net.vad.weight), ptr(self.d_o), ptr(self.d_x1), ptr(self.att_grads),
-                  ptr(self.slab), *dims, st)
+                  ptr(self.slab), *dims, st, nbytes=4 * self.ntok * (2 * self.hd + 7 * self.d_model))
         g = self.att_grads
         o = 0
         for t, n in ((ff.w_2.weight, D * D), (ff.w_1.weight, D * D), (sa.fc.weight, D * hd), (ff.layer_norm.weight, D),
@@ -335,10 +336,12 @@ class DenoiserPlan:
             G(t).view(-1).copy_(g[o:o + n])
             o += n
         _lib.call("noise_attn_core_bwd", ptr(self.qkv), ptr(self.d_o), ptr(self.ml), ptr(self.keep), self.seed,
-                  float(self.p_drop if self.keep is None else ATTN_DROPOUT), ptr(self.d_qkv), *dims, st)
+                  float(self.p_drop if self.keep is None else ATTN_DROPOUT), ptr(self.d_qkv), *dims, st,
+                  nbytes=4 * self.ntok * 7 * self.hd)
         _lib.call("noise_attn_pre_bwd", ptr(self.d_qkv), ptr(self.d_x1), ptr(self.xhat0), ptr(self.rstd0),
                   ptr(att.layer_norm.weight), ptr(att.layer_norm.bias), ptr(sa.w_qs.weight), ptr(sa.w_ks.weight),
-                  ptr(sa.w_vs.weight), ptr(self.d_x0), ptr(self.att_grads), ptr(self.slab), *dims, st)
+                  ptr(sa.w_vs.weight), ptr(self.d_x0), ptr(self.att_grads), ptr(self.slab), *dims, st,
+                  nbytes=4 * self.ntok * (3 * self.hd + 3 * self.d_model))
         o = 0
         for t, n in ((sa.w_qs.weight, hd * D), (sa.w_ks.weight, hd * D), (sa.w_vs.weight, hd * D),
                      (att.layer_norm.weight, D), (att.layer_norm.bias, D)):

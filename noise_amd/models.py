@@ -405,11 +405,11 @@ class VADSpectralV2(_LightningModule):
         import ctypes
         n_spec, n_wave = ctypes.c_int(0), ctypes.c_int(0)
         g = want_grad
-        _lib.call("noise_vad_label", ptr(clean), ptr(bufs["label"]), B, seg, 160, st)
+        _lib.call("noise_vad_label", ptr(clean), ptr(bufs["label"]), B, seg, 160, st, nbytes=4 * B * seg)
         _lib.call("noise_spectral_l1", ptr(enh), ptr(lm_c), ptr(bufs["d_enh"]) if g else None, ptr(bufs["spec_partial"]),
-                  ctypes.byref(n_spec), B * H * W, st)
+                  ctypes.byref(n_spec), B * H * W, st, nbytes=4 * B * H * W * (3 if g else 2))
         _lib.call("noise_wave_pair_l1", ptr(wave), ptr(clean), ptr(bufs["d_wave"]) if g else None,
-                  ptr(bufs["wave_partial"]), ctypes.byref(n_wave), B, seg, st)
+                  ptr(bufs["wave_partial"]), ctypes.byref(n_wave), B, seg, st, nbytes=4 * B * seg * (3 if g else 2))
         _lib.call("noise_loss_finalize", ptr(bufs["spec_partial"]), n_spec.value, B * H * W, ptr(bufs["wave_partial"]),
                   n_wave.value, B, seg, ptr(vad), ptr(bufs["label"]), ptr(bufs["d_vad"]) if g else None, ptr(bufs["out4"]),
                   st)

@@ -40,6 +40,10 @@ def _src(s):
     return ptr(y), ptr(coef), int(bool(relu6))
 
 
+def _nsrc(b):
+    return 2 if (b is not None and b[0] is not None) else 1
+
+
 def conv_out(n, s, transposed):
     return (n - 1) * s + 1 if transposed else (n - 1) // s + 1
 
@@ -48,37 +52,43 @@ def dw3x3_fwd(a, b, w, out, slab, transposed, B, Hi, Wi, C, stride):
     """Returns the number of slab rows written (0 when slab is None)."""
     rows = ctypes.c_int(0)
     _lib.call("noise_dw3x3_fwd", *_src(a), *_src(b), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows),
-              int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream())
+              int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream(),
+              nbytes=4 * C * (B * Hi * Wi * _nsrc(b) + out.numel() // C))
     return rows.value
 
 
 def dw3x3_bwd(grad, a, b, w, g_in, dw, scratch, transposed, B, Hi, Wi, C, stride):
     dz, y, coef3 = grad
     _lib.call("noise_dw3x3_bwd", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(w), ptr(g_in), ptr(dw),
-              ptr(scratch), int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream())
+              ptr(scratch), int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream(),
+              nbytes=4 * C * (B * Hi * Wi * (_nsrc(b) + 1)) + dz.numel() * 4 * (2 if coef3 is not None else 1))
 
 
 def first_conv_fwd(logmag, absmax, w, out, slab, B, H, W, hp, wp, pad_value, C, stride):
     rows = ctypes.c_int(0)
     _lib.call("noise_first_conv_fwd", ptr(logmag), ptr(absmax), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows),
-              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream())
+              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream(),
+              nbytes=4 * (B * H * W + out.numel()))
     return rows.value
 
 
 def first_conv_wgrad(grad, logmag, absmax, dw, scratch, B, H, W, hp, wp, pad_value, C, stride):
     dz, y, coef3 = grad
     _lib.call("noise_first_conv_wgrad", ptr(dz), ptr(y), ptr(coef3), ptr(logmag), ptr(absmax), ptr(dw), ptr(scratch),
-              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream())
+              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream(),
+              nbytes=4 * (B * H * W + dz.numel() * (2 if coef3 is not None else 1)))
 
 
 def last_convT_fwd(a, b, w, bias, logmag, absmax, enh, filt, B, Hi, Wi, C, stride, H, W):
     _lib.call("noise_last_convT_fwd", *_src(a), *_src(b), ptr(w), ptr(bias), ptr(logmag), ptr(absmax), ptr(enh),
-              ptr(filt), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream())
+              ptr(filt), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream(),
+              nbytes=4 * (B * Hi * Wi * C * _nsrc(b) + 2 * B * H * W))
 
 
 def last_convT_bwd(d_enh, enh, absmax, a, b, w, g_in, dw, dbias, scratch, B, Hi, Wi, C, stride, H, W):
     _lib.call("noise_last_convT_bwd", ptr(d_enh), ptr(enh), ptr(absmax), *_src(a), *_src(b), ptr(w), ptr(g_in),
-              ptr(dw), ptr(dbias), ptr(scratch), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream())
+              ptr(dw), ptr(dbias), ptr(scratch), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream(),
+              nbytes=4 * (B * Hi * Wi * C * (_nsrc(b) + 1) + 2 * B * H * W))
 
 
 def bn_finalize_fwd(slab, rows, C, count, gamma, beta, running_mean, running_var, nbt, coef, momentum=0.1, eps=1e-5):
@@ -93,23 +103,24 @@ def bn_coef_eval(C, gamma, beta, running_mean, running_var, coef, eps=1e-5):
 
 def bn_bwd(g1, g2, y, coef, relu6, gamma, dz, dgamma, dbeta, coef3, scratch, npix, C):
     _lib.call("noise_bn_bwd", ptr(g1), ptr(g2), ptr(y), ptr(coef), int(bool(relu6)), ptr(gamma), ptr(dz), ptr(dgamma),
-              ptr(dbeta), ptr(coef3), ptr(scratch), npix, C, _lib.stream())
+              ptr(dbeta), ptr(coef3), ptr(scratch), npix, C, _lib.stream(),
+              nbytes=4 * npix * C * (2 + (g2 is not None) + (dz is not None)))
 
 
 def pw_fwd(a, b, w, out, slab, npix, K, N):
     rows = ctypes.c_int(0)
     _lib.call("noise_pw_fwd", *_src(a), *_src(b), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows), npix, K, N,
-              _lib.stream())
+              _lib.stream(), nbytes=4 * npix * (K * _nsrc(b) + N))
     return rows.value
 
 
 def pw_dgrad(grad, w, add, g_in, npix, Cout, Cin):
     dz, y, coef3 = grad
     _lib.call("noise_pw_dgrad", ptr(dz), ptr(y), ptr(coef3), ptr(w), ptr(add), ptr(g_in), npix, Cout, Cin,
-              _lib.stream())
+              _lib.stream(), nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin * (2 if add is not None else 1)))
 
 
 def pw_wgrad(grad, a, b, dw, scratch, npix, Cout, Cin):
     dz, y, coef3 = grad
     _lib.call("noise_pw_wgrad", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(dw), ptr(scratch), npix, Cout,
-              Cin, _lib.stream())
+              Cin, _lib.stream(), nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin * _nsrc(b)))

@@ -31,7 +31,8 @@ class FusedAdamW:
         flat, grads = self._state()
         _lib.require_cuda(flat)
         _lib.call("noise_adamw_step", ptr(flat), ptr(grads), ptr(self._m), ptr(self._v), ptr(self._step), flat.numel(),
-                  self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), _lib.stream())
+                  self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), _lib.stream(),
+                  nbytes=28 * flat.numel())
 
     def state_dict(self):
         self._state()

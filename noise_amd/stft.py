@@ -118,7 +118,8 @@ class STFT(torch.nn.Module):
         phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32)
         absmax = torch.empty(B, device=wave.device, dtype=torch.float32) if return_absmax else None
         _lib.call("noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisT), _lib.ptr(logmag), _lib.ptr(phase),
-                  _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream())
+                  _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream(),
+                  nbytes=4 * B * L + 8 * B * self.cutoff * T)
         if return_absmax:
             return logmag, phase, absmax
         return logmag, phase
@@ -133,7 +134,7 @@ class STFT(torch.nn.Module):
         out = torch.empty(B, 1, 1, n_out, device=lm.device, dtype=torch.float32)
         _lib.call("noise_istft_fwd", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(self.inverse_basis),
                   _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft,
-                  self.hop_length, _lib.stream())
+                  self.hop_length, _lib.stream(), nbytes=8 * B * F * T + 4 * B * n_out)
         return out
 
     def _inverse_bwd(self, grad_out, out, log_magnitude, phase, d_lm=None, accumulate=False):
@@ -144,7 +145,8 @@ class STFT(torch.nn.Module):
             d_lm = torch.empty_like(log_magnitude, dtype=torch.float32)
         _lib.call("noise_istft_bwd", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
                   _lib.ptr(phase.contiguous()), _lib.ptr(inv_basisT), _lib.ptr(self.window_sum), _lib.ptr(d_lm),
-                  int(accumulate), B, T, self.n_fft, self.hop_length, _lib.stream())
+                  int(accumulate), B, T, self.n_fft, self.hop_length, _lib.stream(),
+                  nbytes=8 * g.numel() + (12 + 4 * int(accumulate)) * B * F * T)
         return d_lm
 
     def inverse(self, log_magnitude, phase):
