@@ -9,9 +9,10 @@
  *   - launches are asynchronous on `stream` (a hipStream_t passed as void*);
  *   - return 0 on success; otherwise nothing was launched and noise_last_error() describes why;
  *   - activations are NHWC fp32; spectra are [B][F][T] fp32; waveforms [B][L] fp32;
- *   - "lazy source" (y, coef, relu6): a = act(coef[c]*y + coef[C+c]) with coef = [scale|shift|mean|invstd]
- *     (coef may be NULL: a = y);  "lazy gradient" (dz, y, coef3): dy = coef3[c]*dz + coef3[C+c]*y + coef3[2C+c]
- *     (coef3 may be NULL: dy = dz).
+ *   - "lazy source" (y, coef, relu6): a = act(coef[c]*y + coef[C+c]) with
+ *     coef = [scale|shift|mean|invstd|mean_lo] (5*C floats; may be NULL: a = y);
+ *     "lazy gradient" (dz, y, coef3): dy = s*(dz - k1) + a2*(y - mean) with
+ *     coef3 = [s|k1_hi|k1_lo|a2|mean_hi|mean_lo] (6*C floats; may be NULL: dy = dz).
  */
 #ifndef NOISE_HIP_H
 #define NOISE_HIP_H

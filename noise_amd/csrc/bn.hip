@@ -2,11 +2,11 @@
 // created through Conv2dNormActivation / InvertedResidual, :371-397, :1151-1159).
 //
 // forward  : per-workgroup (sum, sum-of-squares) partials written by the conv kernels are folded
-//            into [scale | shift | mean | invstd] and the running statistics are updated
+//            into [scale | shift | mean | invstd | mean_lo] and the running statistics are updated
 //            (momentum 0.1, unbiased running variance, num_batches_tracked += 1).
 // backward : one pass over (g1 [+ g2], y) applies the ReLU6 mask, writes dz and the partial sums
-//            of dz and dz*xhat; the finalize kernel turns them into dgamma, dbeta and the three
-//            per-channel coefficients with which consumers rebuild dL/dy = s*dz + alpha*y + beta.
+//            of dz and dz*xhat; the finalize kernel turns them into dgamma, dbeta and the six
+//            per-channel coefficients with which consumers rebuild dL/dy (see LazyGrad in common.h).
 #include "lazy.h"
 
 namespace {
@@ -32,6 +32,7 @@ __global__ void bn_finalize_fwd_kernel(const float* __restrict__ slab, int nrows
   coef[C + c] = beta[c] - (float)mean * sc;
   coef[2 * C + c] = (float)mean;
   coef[3 * C + c] = invstd;
+  coef[4 * C + c] = (float)(mean - (double)(float)mean);   // low part of the batch mean (used by the backward pass)
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -51,6 +52,7 @@ __global__ void bn_coef_eval_kernel(int C, const float* __restrict__ gamma, cons
   coef[C + c] = beta[c] - running_mean[c] * sc;
   coef[2 * C + c] = running_mean[c];
   coef[3 * C + c] = invstd;
+  coef[4 * C + c] = 0.f;
 }
 
 // dz = (g1 + g2) * [0 < scale*y+shift < 6]   (mask only when relu6);  partials of sum dz, sum dz*xhat
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (pl < PPB) {
     const int c = 4 * cg;
     const float4 sc = ld4(coef + c), sh = ld4(coef + C + c), mean = ld4(coef + 2 * C + c), istd = ld4(coef + 3 * C + c);
+    const float4 mlo = ld4(coef + 4 * C + c);
     for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
       const size_t off = (size_t)pix * C + c;
       float4 g = ld4(g1 + off);
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
       }
       if (dz) st4(dz + off, g);
-      const float4 xh = make_float4((yv.x - mean.x) * istd.x, (yv.y - mean.y) * istd.y, (yv.z - mean.z) * istd.z,
-                                    (yv.w - mean.w) * istd.w);
+      const float4 xh = make_float4(((yv.x - mean.x) - mlo.x) * istd.x, ((yv.y - mean.y) - mlo.y) * istd.y,
+                                    ((yv.z - mean.z) - mlo.z) * istd.z, ((yv.w - mean.w) - mlo.w) * istd.w);
       s1 = s1 + g;
       s2 = fma4(g, xh, s2);
     }
@@ -109,13 +112,17 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nrows
   }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
-  const double mean = coef[2 * C + c], istd = coef[3 * C + c];
+  const double mean = (double)coef[2 * C + c] + (double)coef[4 * C + c], istd = coef[3 * C + c];
   const double s = (double)gamma[c] * istd;
   const double k1 = s1 / count, k2 = s2 / count;
-  // dy = s*(dz - k1 - xhat*k2),  xhat = (y - mean)*istd
+  // dy = s*(dz - k1) - s*k2*istd*(y - mean);  k1 and mean as hi+lo float pairs
+  const float k1h = (float)k1, mh = (float)mean;
   coef3[c] = (float)s;
-  coef3[C + c] = (float)(-s * k2 * istd);
-  coef3[2 * C + c] = (float)(-s * k1 + s * k2 * istd * mean);
+  coef3[C + c] = k1h;
+  coef3[2 * C + c] = (float)(k1 - (double)k1h);
+  coef3[3 * C + c] = (float)(-s * k2 * istd);
+  coef3[4 * C + c] = mh;
+  coef3[5 * C + c] = (float)(mean - (double)mh);
 }
 
 }  // namespace

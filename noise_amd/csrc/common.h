@@ -56,10 +56,10 @@ struct LazySrc {
   int relu6;
 };
 
-// Gradient w.r.t. a raw conv output, reconstructed on the fly:
-//     dy[p][c] = s[c]*dz[p][c] + alpha[c]*y[p][c] + beta[c]
-// where dz is the (ReLU6-masked) gradient w.r.t. the BatchNorm output.  `coef3` points at
-// [s(C) | alpha(C) | beta(C)] or is null when dy == dz (no BatchNorm after the conv).
+// Gradient w.r.t. a raw conv output, reconstructed on the fly (BatchNorm backward, centred form):
+//     dy[p][c] = s[c]*(dz[p][c] - k1[c]) + a2[c]*(y[p][c] - mean[c])
+// where dz is the (ReLU6-masked) gradient w.r.t. the BatchNorm output.  `coef3` points at six vectors
+// [s | k1_hi | k1_lo | a2 | mean_hi | mean_lo] (C floats each) or is null when dy == dz.
 struct LazyGrad {
   const float* dz;
   const float* y;

@@ -45,12 +45,19 @@ __device__ __forceinline__ float4 lazy4_at(const Lazy4& s, size_t off) {
 }
 
 // Per-thread view of a lazy gradient restricted to 4 consecutive channels.
+// coef3 holds six per-channel vectors [s | k1_hi | k1_lo | a2 | mean_hi | mean_lo] and
+//     dy = s*((dz - k1_hi) - k1_lo) + a2*((y - mean_hi) - mean_lo)
+// i.e. BatchNorm backward in its centred form.  k1 (the mean of dz) and the batch mean are carried as
+// hi+lo float pairs: when the incoming gradient is nearly constant over the pixels, dz - k1 is a small
+// difference of close numbers and a single-float k1 would cap the accuracy of dy at eps*|k1|.
 struct LazyGrad4 {
   const float* dz;
   const float* y;
-  float4 s, alpha, beta;
+  float4 s, k1h, k1l, a2, mh, ml;
   bool affine;
 };
+
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 __device__ __forceinline__ LazyGrad4 lazygrad4_init(const LazyGrad& g, int C, int c) {
   LazyGrad4 r;
@@ -58,20 +65,28 @@ __device__ __forceinline__ LazyGrad4 lazygrad4_init(const LazyGrad& g, int C, in
   r.y = g.y;
   r.affine = g.coef3 != nullptr;
   r.s = f4(1.f);
-  r.alpha = f4(0.f);
-  r.beta = f4(0.f);
+  r.k1h = r.k1l = r.a2 = r.mh = r.ml = f4(0.f);
   if (r.affine) {
     r.s = ld4(g.coef3 + c);
-    r.alpha = ld4(g.coef3 + C + c);
-    r.beta = ld4(g.coef3 + 2 * C + c);
+    r.k1h = ld4(g.coef3 + C + c);
+    r.k1l = ld4(g.coef3 + 2 * C + c);
+    r.a2 = ld4(g.coef3 + 3 * C + c);
+    r.mh = ld4(g.coef3 + 4 * C + c);
+    r.ml = ld4(g.coef3 + 5 * C + c);
   }
   return r;
 }
 
 __device__ __forceinline__ float4 lazygrad4_at(const LazyGrad4& g, size_t off) {
-  float4 d = ld4(g.dz + off);
+  const float4 d = ld4(g.dz + off);
   if (!g.affine) return d;
-  return fma4(g.s, d, fma4(g.alpha, ld4(g.y + off), g.beta));
+  const float4 t1 = sub4(sub4(d, g.k1h), g.k1l);
+  const float4 t2 = sub4(sub4(ld4(g.y + off), g.mh), g.ml);
+  return fma4(g.a2, t2, g.s * t1);
+}
+
+__device__ __forceinline__ float lazygrad1(float dz, float y, float s, float k1h, float k1l, float a2, float mh, float ml) {
+  return fmaf(a2, (y - mh) - ml, s * ((dz - k1h) - k1l));
 }
 
 // Gather geometry of a 3x3, pad-1 stencil along one axis.

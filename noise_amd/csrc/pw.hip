@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, Laz
   const int p = lane & 15, q = lane >> 4;
   const int K = d.K, N = d.N;
   float* wfrag = lds;                    // [MT][KC][64][4]
-  float* cf = lds + MT * KC * 256;       // [4][KC*16]
+  float* cf = lds + MT * KC * 256;       // [4][KC*16] (forward) or [6][KC*16] (gradient)
   constexpr int KP = KC * 16;
   for (int idx = tid; idx < MT * KC * 256; idx += 256) {
     const int r = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, Laz
     const bool in = k < K;
     if (GRAD) {
       cf[k] = (in && G.coef3) ? G.coef3[k] : 1.f;
-      cf[KP + k] = (in && G.coef3) ? G.coef3[K + k] : 0.f;
-      cf[2 * KP + k] = (in && G.coef3) ? G.coef3[2 * K + k] : 0.f;
+#pragma unroll
+      for (int j = 1; j < 6; ++j) cf[j * KP + k] = (in && G.coef3) ? G.coef3[j * K + k] : 0.f;
     } else {
       cf[k] = (in && A.coef) ? A.coef[k] : 1.f;
       cf[KP + k] = (in && A.coef) ? A.coef[K + k] : 0.f;
@@ -71,7 +71,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, Laz
         const size_t off = (size_t)pix * K + ci;
         if (GRAD) {
           v = ld4(G.dz + off);
-          if (G.coef3) v = fma4(ld4(cf + ci), v, fma4(ld4(cf + KP + ci), ld4(G.y + off), ld4(cf + 2 * KP + ci)));
+          if (G.coef3) {
+            const float4 t1 = sub4(sub4(v, ld4(cf + KP + ci)), ld4(cf + 2 * KP + ci));
+            const float4 t2 = sub4(sub4(ld4(G.y + off), ld4(cf + 4 * KP + ci)), ld4(cf + 5 * KP + ci));
+            v = fma4(ld4(cf + 3 * KP + ci), t2, ld4(cf + ci) * t1);
+          }
         } else {
           v = fma4(ld4(A.y + off), ld4(cf + ci), ld4(cf + KP + ci));
           if (A.relu6) v = relu6_4(v);
@@ -145,15 +149,18 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, La
   extern __shared__ float lds[];  // [N][K] cross-wave reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  float gs[MT], ga[MT], gb[MT];
+  float gs[MT], gk1h[MT], gk1l[MT], ga2[MT], gmh[MT], gml[MT];
   float as[NT], at[NT], bs[NT], bt[NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int co = 16 * m + i;
     const bool in = co < N && G.coef3;
     gs[m] = in ? G.coef3[co] : 1.f;
-    ga[m] = in ? G.coef3[N + co] : 0.f;
-    gb[m] = in ? G.coef3[2 * N + co] : 0.f;
+    gk1h[m] = in ? G.coef3[N + co] : 0.f;
+    gk1l[m] = in ? G.coef3[2 * N + co] : 0.f;
+    ga2[m] = in ? G.coef3[3 * N + co] : 0.f;
+    gmh[m] = in ? G.coef3[4 * N + co] : 0.f;
+    gml[m] = in ? G.coef3[5 * N + co] : 0.f;
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, La
       if (valid && co < N) {
         const size_t off = (size_t)pix * N + co;
         v = G.dz[off];
-        if (G.coef3) v = fmaf(gs[m], v, fmaf(ga[m], G.y[off], gb[m]));
+        if (G.coef3) v = lazygrad1(v, G.y[off], gs[m], gk1h[m], gk1l[m], ga2[m], gmh[m], gml[m]);
       }
       dy[m] = v;
     }
@@ -243,7 +250,7 @@ __global__ void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows,
 template <bool GRAD, int KC, int MT>
 void launch_pw(LazySrc A, LazySrc Bs, LazyGrad G, const float* W, const float* add, float* out, float* slab, PwDims d,
                int grid, hipStream_t st) {
-  size_t smem = (size_t)(MT * KC * 256 + 4 * KC * 16) * sizeof(float);
+  size_t smem = (size_t)(MT * KC * 256 + 6 * KC * 16) * sizeof(float);
   const size_t red = (size_t)8 * MT * 16 * sizeof(float);
   if (red > smem) smem = red;
   hipLaunchKernelGGL((pw_gemm_kernel<GRAD, KC, MT>), dim3(grid), dim3(256), smem, st, A, Bs, G, W, add, out, slab, d);

@@ -80,8 +80,8 @@ class DenoiserPlan:
             r = _Rec(name=name, kind=kind, conv=conv, bn=bn, relu6=relu6, C=C, Cin=Cin, B=B, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo,
                      stride=stride, transposed=transposed)
             r.y = torch.empty(B, Ho, Wo, C, **f32)
-            r.coef = torch.empty(4 * C, **f32)
-            r.coef3 = torch.empty(3 * C, **f32)
+            r.coef = torch.empty(5 * C, **f32)
+            r.coef3 = torch.empty(6 * C, **f32)
             self.recs.append(r)
             return r
 

@@ -1,8 +1,9 @@
 """Thin Python wrappers over the C-ABI entry points of the denoiser kernels.
 
 Tensors are NHWC fp32 CUDA tensors.  A "lazy source" is a tuple (y, coef, relu6): the raw conv
-output, the [scale|shift|mean|invstd] coefficient vector of the BatchNorm that follows it (or None)
-and whether a ReLU6 follows.  A "lazy gradient" is (dz, y, coef3) with coef3 = [s|alpha|beta] or None.
+output, the [scale|shift|mean|invstd|mean_lo] coefficient vector of the BatchNorm that follows it (or
+None) and whether a ReLU6 follows.  A "lazy gradient" is (dz, y, coef3) with
+coef3 = [s|k1_hi|k1_lo|a2|mean_hi|mean_lo] or None: dy = s*(dz - k1) + a2*(y - mean).
 """
 import ctypes
 

@@ -30,7 +30,20 @@ def rand_coef(C, g):
     mean = 0.3 * torch.randn(C, generator=g)
     invstd = 0.5 + torch.rand(C, generator=g)
     scale = gamma * invstd
-    return torch.cat([scale, beta - mean * scale, mean, invstd])
+    return torch.cat([scale, beta - mean * scale, mean, invstd, torch.zeros(C)])
+
+
+def rand_gcoef(C, g):
+    """[s | k1_hi | k1_lo | a2 | mean_hi | mean_lo] of a made-up BatchNorm backward."""
+    v = torch.randn(6 * C, generator=g) * 0.5
+    v[2 * C:3 * C] *= 1e-7
+    v[5 * C:] *= 1e-7
+    return v
+
+
+def gcoef_apply(c6, dz, y, C, chan_view):
+    s, k1h, k1l, a2, mh, ml = (c6[i * C:(i + 1) * C].view(chan_view) for i in range(6))
+    return s * (dz - k1h - k1l) + a2 * (y - mh - ml)
 
 
 def lazy_ref(y, coef, relu6):
@@ -95,8 +108,8 @@ def test_depthwise(dev, C, stride, transposed, two_src, shape):
 
     # backward with a lazy gradient dy = s*dz + alpha*y + beta
     dz = torch.randn(ref.shape, generator=g)
-    c3 = torch.randn(3 * C, generator=g) * 0.5
-    dy = c3[:C].view(1, C, 1, 1) * dz + c3[C:2 * C].view(1, C, 1, 1) * ref.detach() + c3[2 * C:].view(1, C, 1, 1)
+    c3 = rand_gcoef(C, g)
+    dy = gcoef_apply(c3, dz, ref.detach(), C, (1, C, 1, 1))
     ref.backward(dy)
     g_in = torch.empty(B, Hi, Wi, C, device=dev)
     dw = torch.empty(C, 1, 3, 3, device=dev)
@@ -142,8 +155,8 @@ def test_pointwise(dev, K, N, npix, two_src):
     close(s2, (ref.detach().double() ** 2).sum(0), 1e-4, "sumsq")
 
     dz = torch.randn(npix, N, generator=g)
-    c3 = torch.randn(3 * N, generator=g) * 0.5
-    dy = c3[:N] * dz + c3[N:2 * N] * ref.detach() + c3[2 * N:]
+    c3 = rand_gcoef(N, g)
+    dy = gcoef_apply(c3, dz, ref.detach(), N, (N,))
     ref.backward(dy)
     other = torch.randn(npix, K, generator=g)
     g_in = torch.empty(npix, K, device=dev)
@@ -238,7 +251,7 @@ def test_batchnorm_train(dev, C, relu6, two):
     # forward finalize from (sum, sumsq) partials
     yd = nhwc(y.detach()).to(dev)
     slab = torch.stack([yd.view(npix, C).sum(0), (yd.view(npix, C) ** 2).sum(0)]).view(-1).contiguous()
-    coef = torch.empty(4 * C, device=dev)
+    coef = torch.empty(5 * C, device=dev)
     rm_d, rv_d = rm.to(dev), rv.to(dev)
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
     ops.bn_finalize_fwd(slab, 1, C, npix, gamma.detach().to(dev), beta.detach().to(dev), rm_d, rv_d, nbt, coef)
@@ -252,13 +265,13 @@ def test_batchnorm_train(dev, C, relu6, two):
     g2 = torch.randn(a.shape, generator=g) if two else None
     a.backward(g1 + g2 if two else g1)
     dz = torch.empty(B, H, W, C, device=dev)
-    dgamma, dbeta, coef3 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(3 * C, device=dev)
+    dgamma, dbeta, coef3 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(6 * C, device=dev)
     scratch = torch.empty(ops.CONV_MAX_BLOCKS * 2 * C, device=dev)
     ops.bn_bwd(nhwc(g1).to(dev), nhwc(g2).to(dev) if two else None, yd, coef, relu6, gamma.detach().to(dev), dz,
                dgamma, dbeta, coef3, scratch, npix, C)
     close(dgamma, gamma.grad, 1e-4, "dgamma")
     close(dbeta, beta.grad, 1e-4, "dbeta")
-    dy = coef3[:C] * dz + coef3[C:2 * C] * yd + coef3[2 * C:]
+    dy = gcoef_apply(coef3, dz, yd, C, (C,))
     close(nchw(dy), y.grad, 1e-4, "dy")
     # eval-mode coefficients
     ops.bn_coef_eval(C, gamma.detach().to(dev), beta.detach().to(dev), rm_d, rv_d, coef)
