@@ -11,18 +11,17 @@
 
 namespace {
 
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ slab, int nrows, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ running_mean, float* __restrict__ running_var,
-                                       long long* __restrict__ num_batches_tracked, float momentum, float eps,
-                                       float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrows; ++r) {
-    s1 += (double)slab[(size_t)r * 2 * C + c];
-    s2 += (double)slab[(size_t)r * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ slab, int nrows, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              long long* __restrict__ num_batches_tracked, float momentum,
+                                                              float eps, float* __restrict__ coef) {
+  __shared__ double red[256];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool ok = c < C;
+  const double s1 = slab_column_sum(slab, nrows, 2 * C, c, ok, red);
+  const double s2 = slab_column_sum(slab, nrows, 2 * C, C + c, ok, red);
+  if (threadIdx.x >= 32 || !ok) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -100,16 +99,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nrows, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ coef,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef3) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrows; ++r) {
-    s1 += (double)slab[(size_t)r * 2 * C + c];
-    s2 += (double)slab[(size_t)r * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nrows, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ coef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef3) {
+  __shared__ double red[256];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool ok = c < C;
+  const double s1 = slab_column_sum(slab, nrows, 2 * C, c, ok, red);
+  const double s2 = slab_column_sum(slab, nrows, 2 * C, C + c, ok, red);
+  if (threadIdx.x >= 32 || !ok) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   const double mean = (double)coef[2 * C + c] + (double)coef[4 * C + c], istd = coef[3 * C + c];
@@ -132,7 +131,7 @@ NOISE_EXPORT int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, 
                                        long long* num_batches_tracked, float momentum, float eps, float* coef,
                                        void* stream) {
   NOISE_REQUIRE(slab && gamma && beta && coef && C > 0 && slab_rows > 0 && count > 0, "noise_bn_finalize_fwd: bad argument");
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, slab, slab_rows, C,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, slab, slab_rows, C,
                      (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, coef);
   NOISE_CHECK_LAUNCH("noise_bn_finalize_fwd");
   return 0;
@@ -160,7 +159,7 @@ NOISE_EXPORT int noise_bn_bwd(const float* g1, const float* g2, const float* y, 
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float), st, g1, g2, y, coef,
                      relu6, C, npix, dz, scratch);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, st, scratch, grid, C, (double)npix, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, st, scratch, grid, C, (double)npix, gamma,
                      coef, dgamma, dbeta, coef3);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/finalize");
   return 0;

@@ -87,4 +87,34 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// Column sums of a [nrows][row_stride] fp32 slab in double.  Call with 256 threads laid out as
+// 32 columns x 8 row lanes (col = first_col + (tid & 31), row lane = tid >> 5): reads are 128-byte
+// coalesced and every thread walks nrows/8 rows.  `red` is 256 doubles of LDS; the result is valid in
+// the threads with tid < 32.  Contains barriers: every thread of the block must call it.
+__device__ __forceinline__ double slab_column_sum(const float* __restrict__ slab, int nrows, int row_stride, int col,
+                                                  bool col_valid, double* red) {
+  const int rl = threadIdx.x >> 5;
+  double s = 0.0;
+  if (col_valid) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep several loads in flight
+    int r = rl;
+    for (; r + 24 < nrows; r += 32) {
+      s0 += (double)slab[(size_t)r * row_stride + col];
+      s1 += (double)slab[(size_t)(r + 8) * row_stride + col];
+      s2 += (double)slab[(size_t)(r + 16) * row_stride + col];
+      s3 += (double)slab[(size_t)(r + 24) * row_stride + col];
+    }
+    for (; r < nrows; r += 8) s0 += (double)slab[(size_t)r * row_stride + col];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[threadIdx.x + 32 * k];
+  }
+  return s;
+}
 #endif

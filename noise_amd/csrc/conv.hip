@@ -52,11 +52,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(LazySrc A, LazySrc Bsrc, co
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const long npix = (long)d.B * d.Ho * d.Wo;
-    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
-      const int ox = (int)(pix % d.Wo);
-      const long r = pix / d.Wo;
-      const int oy = (int)(r % d.Ho), bi = (int)(r / d.Ho);
+    const int npix = d.B * d.Ho * d.Wo;
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int ox = pix % d.Wo;
+      const int r = pix / d.Wo;
+      const int oy = r % d.Ho, bi = r / d.Ho;
       float4 acc = f4(0.f);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const long npix = (long)d.B * d.Hi * d.Wi;
-    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
-      const int ix = (int)(pix % d.Wi);
-      const long r = pix / d.Wi;
-      const int iy = (int)(r % d.Hi), bi = (int)(r / d.Hi);
+    const int npix = d.B * d.Hi * d.Wi;
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int ix = pix % d.Wi;
+      const int r = pix / d.Wi;
+      const int iy = r % d.Hi, bi = r / d.Hi;
       const size_t ioff = (size_t)pix * C + c;
       float4 av = lazy4_at(a, ioff);
       if (b.present) av = av + lazy4_at(b, ioff);
@@ -163,11 +163,11 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const long npix = (long)d.B * d.Ho * d.Wo;
-    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
-      const int ox = (int)(pix % d.Wo);
-      const long r = pix / d.Wo;
-      const int oy = (int)(r % d.Ho), bi = (int)(r / d.Ho);
+    const int npix = d.B * d.Ho * d.Wo;
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int ox = pix % d.Wo;
+      const int r = pix / d.Wo;
+      const int oy = r % d.Ho, bi = r / d.Ho;
       const float mx = absmax[bi] + 1e-6f;
       float4 acc = f4(0.f);
 #pragma unroll
@@ -201,11 +201,11 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(LazyGrad G, const
   if (pl < PPB) {
     const int c = 4 * cg;
     const LazyGrad4 g = lazygrad4_init(G, C, c);
-    const long npix = (long)d.B * d.Ho * d.Wo;
-    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
-      const int ox = (int)(pix % d.Wo);
-      const long r = pix / d.Wo;
-      const int oy = (int)(r % d.Ho), bi = (int)(r / d.Ho);
+    const int npix = d.B * d.Ho * d.Wo;
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int ox = pix % d.Wo;
+      const int r = pix / d.Wo;
+      const int oy = r % d.Ho, bi = r / d.Ho;
       const float mx = absmax[bi] + 1e-6f;
       const float4 dy = lazygrad4_at(g, (size_t)pix * C + c);
 #pragma unroll
@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256) void last_convT_fwd_kernel(LazySrc A, LazySrc 
     cf[3 * C + i] = (Bsrc.y && Bsrc.coef) ? Bsrc.coef[C + i] : 0.f;
   }
   __syncthreads();
-  const long npix = (long)d.B * d.H * d.W;
-  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
-    const int ox = (int)(pix % d.W);
-    const long r = pix / d.W;
-    const int oy = (int)(r % d.H), bi = (int)(r / d.H);
+  const int npix = d.B * d.H * d.W;
+  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += gridDim.x * blockDim.x) {
+    const int ox = pix % d.W;
+    const int r = pix / d.W;
+    const int oy = r % d.H, bi = r / d.H;
     float acc = bias[0];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -285,6 +285,65 @@ __global__ __launch_bounds__(256) void last_convT_fwd_kernel(LazySrc A, LazySrc 
   }
 }
 
+// Same computation with the channel sum spread over the C/4 lanes of a pixel (C/4 a power of two <= 16):
+// every load is a coalesced float4 and the per-pixel dot product finishes with a few lane shuffles.
+__global__ __launch_bounds__(256) void last_convT_fwd_split_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ logmag,
+                                                                   const float* __restrict__ absmax,
+                                                                   float* __restrict__ enh, float* __restrict__ filt_out,
+                                                                   LastDims d) {
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+  float4 wk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
+  const float bv = bias[0];
+  const int npix = d.B * d.H * d.W;
+  const int iters = (npix + gridDim.x * PPB - 1) / (gridDim.x * PPB);   // uniform: the shuffles need whole pixel groups
+  for (int it = 0; it < iters; ++it) {
+    const int pix = (it * gridDim.x + blockIdx.x) * PPB + pl;
+    const bool valid = pix < npix;
+    float acc = 0.f;
+    int bi = 0;
+    if (valid) {
+      const int ox = pix % d.W;
+      const int r = pix / d.W;
+      const int oy = r % d.H;
+      bi = r / d.H;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = tap_src<GEOM_CONVT>(oy + d.oy0, ky, d.sy, d.Hi);
+        if (iy < 0) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = tap_src<GEOM_CONVT>(ox + d.ox0, kx, d.sx, d.Wi);
+          if (ix < 0) continue;
+          const size_t off = (((size_t)bi * d.Hi + iy) * d.Wi + ix) * C + c;
+          float4 v = lazy4_at(a, off);
+          if (b.present) v = v + lazy4_at(b, off);
+          const float4 ww = wk[ky * 3 + kx];
+          acc = fmaf(v.x, ww.x, acc);
+          acc = fmaf(v.y, ww.y, acc);
+          acc = fmaf(v.z, ww.z, acc);
+          acc = fmaf(v.w, ww.w, acc);
+        }
+      }
+    }
+    for (int o = CG >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (valid && cg == 0) {
+      acc += bv;
+      if (filt_out) filt_out[pix] = acc;
+      if (enh) {
+        const float mx = absmax[bi] + 1e-6f;
+        const float v = logmag[pix] / mx + acc;
+        enh[pix] = fminf(fmaxf(v, -1.f), 1.f) * mx;
+      }
+    }
+  }
+}
+
 // Backward of the last layer.  dy0[o] = d_enh[o] * max * [ |enh[o]| < max ]  on the cropped region.
 //   g_in[i][c] = sum_k dy0[i*s - 1 + k] * w[c][k];   dW[c][k] += a[i][c] * dy0[i*s - 1 + k];   db = sum dy0
 __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __restrict__ d_enh, const float* __restrict__ enh,
@@ -303,11 +362,11 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const long npix = (long)d.B * d.Hi * d.Wi;
-    for (long pix = (long)blockIdx.x * PPB + pl; pix < npix; pix += (long)gridDim.x * PPB) {
-      const int ix = (int)(pix % d.Wi);
-      const long r = pix / d.Wi;
-      const int iy = (int)(r % d.Hi), bi = (int)(r / d.Hi);
+    const int npix = d.B * d.Hi * d.Wi;
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int ix = pix % d.Wi;
+      const int r = pix / d.Wi;
+      const int iy = r % d.Hi, bi = r / d.Hi;
       const float mx = absmax[bi] + 1e-6f;
       const size_t ioff = (size_t)pix * C + c;
       float4 av = lazy4_at(a, ioff);
@@ -332,10 +391,10 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
     }
     // bias gradient: every output position is owned by exactly one (pixel lane, cg==0) visit below
     if (cg == 0) {
-      const long nout = (long)d.B * d.H * d.W;
+      const int nout = d.B * d.H * d.W;
       float s = 0.f;
-      for (long o = (long)blockIdx.x * PPB + pl; o < nout; o += (long)gridDim.x * PPB) {
-        const int bi = (int)(o / ((long)d.H * d.W));
+      for (int o = blockIdx.x * PPB + pl; o < nout; o += gridDim.x * PPB) {
+        const int bi = o / (d.H * d.W);
         const float mx = absmax[bi] + 1e-6f;
         const float e = enh[o];
         s += (e > -mx && e < mx) ? d_enh[o] * mx : 0.f;
@@ -347,12 +406,14 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
 }
 
 // out[j] = sum_b slab[b][j]; optional transpose from [k][C] slab rows to the (C,k) parameter layout
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols, int row_stride,
-                                   float* __restrict__ out, int tr_k, int tr_C, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncols) return;
-  double s = 0.0;
-  for (int b = 0; b < nrows; ++b) s += (double)slab[(size_t)b * row_stride + j];
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols,
+                                                          int row_stride, float* __restrict__ out, int tr_k, int tr_C,
+                                                          int accumulate) {
+  __shared__ double red[256];
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool ok = j < ncols;
+  const double s = slab_column_sum(slab, nrows, row_stride, j, ok, red);
+  if (threadIdx.x >= 32 || !ok) return;
   int o = j;
   if (tr_k > 0) {  // j = k*C + c  ->  c*tr_k + k
     const int k = j / tr_C, c = j - k * tr_C;
@@ -365,6 +426,11 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nrows, in
 int conv_grid(long npix, int C) {
   const int PPB = 256 / (C / 4);
   return noise_grid(npix, PPB * 4, 1024);
+}
+
+int check_size(const char* who, long npix, int C) {
+  NOISE_REQUIRE(npix < (1L << 31) - 65536 * 64 && C > 0, "%s: %ld pixels exceed the 32-bit pixel index of this kernel", who, npix);
+  return 0;
 }
 
 int check_c(const char* who, int C) {
@@ -390,6 +456,7 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
   d.Ho = transposed ? (Hi - 1) * sy + 1 : (Hi - 1) / sy + 1;
   d.Wo = transposed ? (Wi - 1) * sx + 1 : (Wi - 1) / sx + 1;
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  if (check_size("noise_dw3x3_fwd", (long)B * d.Ho * d.Wo + (long)B * Hi * Wi, C)) return -1;
   const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
   const int PPB = 256 / (C / 4);
   const size_t smem = (size_t)PPB * 2 * C * sizeof(float);
@@ -419,6 +486,7 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   d.Wo = transposed ? (Wi - 1) * sx + 1 : (Wi - 1) / sx + 1;
   LazyGrad G{dz, y_out, coef3};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  if (check_size("noise_dw3x3_bwd", (long)B * d.Ho * d.Wo + (long)B * Hi * Wi, C)) return -1;
   const int grid = conv_grid((long)B * Hi * Wi, C);
   const int PPB = 256 / (C / 4);
   const size_t smem = (size_t)PPB * 9 * C * sizeof(float);
@@ -429,7 +497,7 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   else
     hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, d);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 256)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
   return 0;
 }
@@ -441,6 +509,7 @@ NOISE_EXPORT int noise_first_conv_fwd(const float* logmag, const float* absmax, 
   NOISE_REQUIRE(B > 0 && H > 0 && W > 0 && hp >= 0 && wp >= 0, "noise_first_conv_fwd: bad shape");
   NOISE_REQUIRE(logmag && absmax && w && out, "noise_first_conv_fwd: null pointer");
   FirstDims d{B, H, W, hp, wp, (H + hp - 1) / sy + 1, (W + wp - 1) / sx + 1, C, sy, sx, pad_value};
+  if (check_size("noise_first_conv_fwd", (long)B * (H + hp) * (W + wp), C)) return -1;
   const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
   const int PPB = 256 / (C / 4);
   if (slab_rows) *slab_rows = grid;
@@ -463,7 +532,7 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
   hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
                      absmax, scratch, d);
   NOISE_CHECK_LAUNCH("noise_first_conv_wgrad");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 256)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_first_conv_wgrad/reduce");
   return 0;
 }
@@ -479,9 +548,17 @@ NOISE_EXPORT int noise_last_convT_fwd(const float* a_y, const float* a_coef, int
   NOISE_REQUIRE(Hfull >= H && Wfull >= W, "noise_last_convT_fwd: output %dx%d smaller than requested crop %dx%d", Hfull, Wfull, H, W);
   LastDims d{B, Hi, Wi, C, sy, sx, H, W, Hfull - H, Wfull - W};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
-  const int grid = noise_grid((long)B * H * W, 256, 4096);
-  hipLaunchKernelGGL(last_convT_fwd_kernel, dim3(grid), dim3(256), (size_t)13 * C * sizeof(float), (hipStream_t)stream, A,
-                     Bs, w, bias, logmag, absmax, enh, filt, d);
+  if (check_size("noise_last_convT_fwd", (long)B * Hfull * Wfull, C)) return -1;
+  const int CG = C / 4;
+  if (CG <= 16 && (CG & (CG - 1)) == 0) {
+    const int grid = noise_grid((long)B * H * W, 256 / CG, 8192);
+    hipLaunchKernelGGL(last_convT_fwd_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
+                       absmax, enh, filt, d);
+  } else {
+    const int grid = noise_grid((long)B * H * W, 256, 4096);
+    hipLaunchKernelGGL(last_convT_fwd_kernel, dim3(grid), dim3(256), (size_t)13 * C * sizeof(float), (hipStream_t)stream, A,
+                       Bs, w, bias, logmag, absmax, enh, filt, d);
+  }
   NOISE_CHECK_LAUNCH("noise_last_convT_fwd");
   return 0;
 }
@@ -503,10 +580,10 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
   hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 10 * C * sizeof(float), st, d_enh, enh,
                      absmax, A, Bs, w, g_in, scratch, d);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(10 * C, 256)), dim3(256), 0, st, scratch, grid, 10 * C, 10 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(10 * C, 32)), dim3(256), 0, st, scratch, grid, 10 * C, 10 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd/reduce");
   // the bias gradient sits at slab column 9*C (slot 9, channel 0)
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(64), 0, st, scratch + 9 * C, grid, 1, 10 * C, dbias, 0, 0, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, scratch + 9 * C, grid, 1, 10 * C, dbias, 0, 0, 0);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd/bias");
   return 0;
 }

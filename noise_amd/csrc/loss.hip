@@ -107,6 +107,84 @@ __global__ __launch_bounds__(256) void wave_pair_l1_kernel(const float* __restri
   if (tid == 0) partial[blockIdx.x] = total;
 }
 
+// Same result in O(B log B) per time sample: sort the B clean values of a sample, prefix-sum them, and
+// every enhanced value finds its rank k by binary search:
+//     sum_j |w - c_j| = w*k - P[k] + (P[B] - P[k2]) - w*(B - k2),   sum_j sign(w - c_j) = k - (B - k2)
+// with k = #{c_j < w}, k2 = #{c_j <= w}.  One workgroup owns WTS time samples; the sorted columns and their
+// double-precision prefix sums live in LDS.
+__global__ __launch_bounds__(256) void wave_pair_sorted_kernel(const float* __restrict__ w, const float* __restrict__ c,
+                                                               int B, int L, int NP, int WTS, float scale,
+                                                               float* __restrict__ d_w, double* __restrict__ partial) {
+  extern __shared__ double lds_d[];
+  double* pd = lds_d;                                        // [WTS][B+1] prefix sums
+  float* cs = reinterpret_cast<float*>(pd + (size_t)WTS * (B + 1));   // [WTS][NP] sorted clean values
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = blockIdx.x * WTS;
+  for (int e = tid; e < WTS * NP; e += 256) {
+    const int tt = e % WTS, j = e / WTS;
+    cs[tt * NP + j] = (j < B && t0 + tt < L) ? c[(size_t)j * L + t0 + tt] : INFINITY;
+  }
+  __syncthreads();
+  // bitonic sort of each row (ascending)
+  const int half = NP >> 1;
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = tid; e < WTS * half; e += 256) {
+        const int row = e / half, p = e - row * half;
+        const int lo = 2 * j * (p / j) + (p % j), hi = lo + j;
+        float* r = cs + row * NP;
+        const float a = r[lo], b = r[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > b) == up) {
+          r[lo] = b;
+          r[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // prefix sums: each wave scans rows wave, wave+4, ...
+  for (int row = wave; row < WTS; row += 4) {
+    double carry = 0.0;
+    if (lane == 0) pd[(size_t)row * (B + 1)] = 0.0;
+    for (int j0 = 0; j0 < B; j0 += 64) {
+      const int j = j0 + lane;
+      double v = j < B ? (double)cs[row * NP + j] : 0.0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+      }
+      if (j < B) pd[(size_t)row * (B + 1) + j + 1] = carry + v;
+      carry += __shfl(v, 63, 64);
+    }
+  }
+  __syncthreads();
+  double total = 0.0;
+  for (int e = tid; e < B * WTS; e += 256) {
+    const int tt = e % WTS, i = e / WTS;
+    const int t = t0 + tt;
+    if (t >= L) continue;
+    const float wv = w[(size_t)i * L + t];
+    const float* r = cs + tt * NP;
+    int lo = 0, hi = B;                    // lower bound: first index with r[idx] >= wv
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (r[mid] < wv) lo = mid + 1; else hi = mid;
+    }
+    const int k = lo;
+    int k2 = k;
+    while (k2 < B && r[k2] == wv) ++k2;
+    const double* P = pd + (size_t)tt * (B + 1);
+    const double wd = (double)wv;
+    total += wd * k - P[k] + (P[B] - P[k2]) - wd * (B - k2);
+    if (d_w) d_w[(size_t)i * L + t] = (float)(k - (B - k2)) * scale;
+  }
+  total = block_sum_d(total, red);
+  if (tid == 0) partial[blockIdx.x] = total;
+}
+
 // out[0..3] = loss, vad_loss, waveform_loss, spectral_loss;  d_vad[b] = (sigmoid(x) - y)/B
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ spec_partial, int n_spec,
                                                             double spec_count, const double* __restrict__ wave_partial,
@@ -177,10 +255,28 @@ NOISE_EXPORT int noise_vad_label(const float* clean, float* label, int B, int L,
   return 0;
 }
 
-// Cross-pair waveform L1 (the reference's broadcast).  partial: ceil(L/16) doubles.
+// Cross-pair waveform L1 (the reference's broadcast).  partial: at least ceil(L/4) doubles.
 NOISE_EXPORT int noise_wave_pair_l1(const float* wave, const float* clean, float* d_wave, double* partial, int* n_partial,
                                     int B, int L, void* stream) {
   NOISE_REQUIRE(wave && clean && partial && B > 0 && L > 0, "noise_wave_pair_l1: bad argument");
+  if (B >= 64 && B <= 2048) {   // sorted algorithm: B log B instead of B^2 per time sample
+    int NP = 64;
+    while (NP < B) NP <<= 1;
+    int WTS = 8;
+    size_t smem = (size_t)WTS * ((size_t)(B + 1) * sizeof(double) + (size_t)NP * sizeof(float));
+    if (smem > 150 * 1024) {
+      WTS = 4;
+      smem = (size_t)WTS * ((size_t)(B + 1) * sizeof(double) + (size_t)NP * sizeof(float));
+    }
+    const int grid = noise_cdiv(L, WTS);
+    if (n_partial) *n_partial = grid;
+    const double cnt = (double)B * (double)B * (double)L;
+    NOISE_ALLOW_LDS(wave_pair_sorted_kernel, smem);
+    hipLaunchKernelGGL(wave_pair_sorted_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, wave, clean, B, L, NP, WTS,
+                       (float)(1.0 / cnt), d_wave, partial);
+    NOISE_CHECK_LAUNCH("noise_wave_pair_l1/sorted");
+    return 0;
+  }
   const int grid = noise_cdiv(L, WT);
   if (n_partial) *n_partial = grid;
   const size_t smem = (size_t)(B < WJ ? B : WJ) * WT * sizeof(float);

@@ -143,76 +143,77 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, Laz
 }
 
 // dW[co][ci] = sum_p dy[p][co] * a[p][ci]:   A[i=co][k=pixel], B[k=pixel][j=ci]; 4 pixels per MFMA.
+// A workgroup stages 64 pixels of dy and a in LDS with coalesced float4 loads (the lazy transforms are
+// applied once, on the way in); each wave then multiplies its 16 pixels against every (co,ci) tile.
+constexpr int WG_TILE = 64;
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, LazySrc Bs, float* __restrict__ slab,
                                                        long npix, int N, int K) {
-  extern __shared__ float lds[];  // [N][K] cross-wave reduction
+  extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  float gs[MT], gk1h[MT], gk1l[MT], ga2[MT], gmh[MT], gml[MT];
-  float as[NT], at[NT], bs[NT], bt[NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int co = 16 * m + i;
-    const bool in = co < N && G.coef3;
-    gs[m] = in ? G.coef3[co] : 1.f;
-    gk1h[m] = in ? G.coef3[N + co] : 0.f;
-    gk1l[m] = in ? G.coef3[2 * N + co] : 0.f;
-    ga2[m] = in ? G.coef3[3 * N + co] : 0.f;
-    gmh[m] = in ? G.coef3[4 * N + co] : 0.f;
-    gml[m] = in ? G.coef3[5 * N + co] : 0.f;
-  }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int ci = 16 * n + i;
-    const bool ina = ci < K && A.coef, inb = ci < K && Bs.y && Bs.coef;
-    as[n] = ina ? A.coef[ci] : 1.f;
-    at[n] = ina ? A.coef[K + ci] : 0.f;
-    bs[n] = inb ? Bs.coef[ci] : 1.f;
-    bt[n] = inb ? Bs.coef[K + ci] : 0.f;
-  }
+  const int pn = N + 4, pk = K + 4;          // LDS row pitches (keep 16-byte alignment)
+  float* dys = lds;                          // [64][pn]
+  float* as = lds + WG_TILE * pn;            // [64][pk]
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const long ngroups = (npix + 3) >> 2;
-  for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
-    const long pix = g * 4 + kq;
-    const bool valid = pix < npix;
-    float dy[MT], av[NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int co = 16 * m + i;
-      float v = 0.f;
-      if (valid && co < N) {
-        const size_t off = (size_t)pix * N + co;
-        v = G.dz[off];
-        if (G.coef3) v = lazygrad1(v, G.y[off], gs[m], gk1h[m], gk1l[m], ga2[m], gmh[m], gml[m]);
-      }
-      dy[m] = v;
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int ci = 16 * n + i;
-      float v = 0.f;
-      if (valid && ci < K) {
-        const size_t off = (size_t)pix * K + ci;
-        v = fmaf(A.y[off], as[n], at[n]);
-        if (A.relu6) v = relu6f(v);
-        if (Bs.y) {
-          float u = fmaf(Bs.y[off], bs[n], bt[n]);
-          if (Bs.relu6) u = relu6f(u);
-          v += u;
+  const int n4 = N >> 2, k4 = K >> 2;
+  const long ntiles = (npix + WG_TILE - 1) / WG_TILE;
+  const long iters = (ntiles + gridDim.x - 1) / gridDim.x;      // uniform trip count: the loop has barriers
+  for (long it = 0; it < iters; ++it) {
+    const long tile = (long)blockIdx.x + it * gridDim.x;
+    const long pix0 = tile * WG_TILE;
+    __syncthreads();
+    for (int e = tid; e < WG_TILE * n4; e += 256) {
+      const int p = e / n4, c = (e - p * n4) * 4;
+      float4 v = f4(0.f);
+      if (tile < ntiles && pix0 + p < npix) {
+        const size_t off = (size_t)(pix0 + p) * N + c;
+        v = ld4(G.dz + off);
+        if (G.coef3) {
+          const float4 t1 = sub4(sub4(v, ld4(G.coef3 + N + c)), ld4(G.coef3 + 2 * N + c));
+          const float4 t2 = sub4(sub4(ld4(G.y + off), ld4(G.coef3 + 4 * N + c)), ld4(G.coef3 + 5 * N + c));
+          v = fma4(ld4(G.coef3 + 3 * N + c), t2, ld4(G.coef3 + c) * t1);
         }
       }
-      av[n] = v;
+      st4(dys + p * pn + c, v);
     }
+    for (int e = tid; e < WG_TILE * k4; e += 256) {
+      const int p = e / k4, c = (e - p * k4) * 4;
+      float4 v = f4(0.f);
+      if (tile < ntiles && pix0 + p < npix) {
+        const size_t off = (size_t)(pix0 + p) * K + c;
+        v = ld4(A.y + off);
+        if (A.coef) v = fma4(v, ld4(A.coef + c), ld4(A.coef + K + c));
+        if (A.relu6) v = relu6_4(v);
+        if (Bs.y) {
+          float4 u = ld4(Bs.y + off);
+          if (Bs.coef) u = fma4(u, ld4(Bs.coef + c), ld4(Bs.coef + K + c));
+          if (Bs.relu6) u = relu6_4(u);
+          v = v + u;
+        }
+      }
+      st4(as + p * pk + c, v);
+    }
+    __syncthreads();
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int s = 0; s < 4; ++s) {
+      const int p = 16 * wave + 4 * s + kq;
+      float dy[MT], av[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[m], av[n], acc[m][n], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) dy[m] = (16 * m + i < N) ? dys[p * pn + 16 * m + i] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) av[n] = (16 * n + i < K) ? as[p * pk + 16 * n + i] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[m], av[n], acc[m][n], 0, 0, 0);
+    }
   }
 
   // D layout: col = ci0 + (lane&15), rows = co0 + 4*(lane>>4) + reg.  Fold the four waves through LDS.
@@ -239,12 +240,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, La
   for (int j = tid; j < N * K; j += 256) slab[(size_t)blockIdx.x * N * K + j] = lds[j];
 }
 
-__global__ void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols, float* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncols) return;
-  double s = 0.0;
-  for (int b = 0; b < nrows; ++b) s += (double)slab[(size_t)b * ncols + j];
-  out[j] = (float)s;
+__global__ __launch_bounds__(256) void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols,
+                                                             float* __restrict__ out) {
+  __shared__ double red[256];
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool ok = j < ncols;
+  const double s = slab_column_sum(slab, nrows, ncols, j, ok, red);
+  if (threadIdx.x < 32 && ok) out[j] = (float)s;
 }
 
 template <bool GRAD, int KC, int MT>
@@ -326,13 +328,16 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
   const int MT = (Cout + 15) / 16, NT = (Cin + 15) / 16;
   LazyGrad G{dz, y_out, coef3};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
-  const int grid = noise_grid(npix, 256, 256);
-  const size_t smem = (size_t)Cout * Cin * sizeof(float);
+  NOISE_REQUIRE(Cout % 4 == 0 && Cin % 4 == 0, "noise_pw_wgrad: channel counts must be multiples of 4");
+  const int grid = noise_grid(npix, WG_TILE, 256);
+  size_t smem = (size_t)WG_TILE * (Cout + Cin + 8) * sizeof(float);
+  if ((size_t)Cout * Cin * sizeof(float) > smem) smem = (size_t)Cout * Cin * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   bool done = false;
 #define X(nt, mt)                                                                                                      \
   if constexpr (mt * nt <= 48) {                                                                                       \
     if (!done && MT == mt && NT == nt) {                                                                               \
+      NOISE_ALLOW_LDS((pw_wgrad_kernel<mt, nt>), smem);                                                                \
       hipLaunchKernelGGL((pw_wgrad_kernel<mt, nt>), dim3(grid), dim3(256), smem, st, G, A, Bs, scratch, npix, Cout, Cin); \
       done = true;                                                                                                     \
     }                                                                                                                  \
@@ -341,7 +346,7 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
 #undef X
   NOISE_REQUIRE(done, "noise_pw_wgrad: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
   NOISE_CHECK_LAUNCH("noise_pw_wgrad");
-  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 256)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
+  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 32)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
   NOISE_CHECK_LAUNCH("noise_pw_wgrad/reduce");
   return 0;
 }
