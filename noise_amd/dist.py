@@ -16,7 +16,8 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # NOISE_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a single-GPU box)
+            backend = os.environ.get("NOISE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
