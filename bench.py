@@ -115,10 +115,11 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.PROFILE = None
     loss = float(out4[0].item())
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
+        on_host = torch.distributed.get_backend() == "gloo"
+        t = torch.tensor([elapsed], device="cpu" if on_host else device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
 
     # ---- per-entry-point HIP-event timing (rank 0): algorithmic bytes / measured time
     fam = {}
@@ -147,7 +148,8 @@ def main():
             "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train_step fwd+bwd+AdamW, 64 x 10 s clips/GPU = 1280 x 0.5 s segments, n_fft 320 hop 160",
+            "config": {"workload": f"train_step fwd+bwd+AdamW, {args.clips} x 10 s clips/GPU = {args.clips * 20} x 0.5 s segments, "
+                                   "n_fft 320 hop 160",
                        "global_batch_clips": world * args.clips, "segments_per_gpu": args.clips * clip_len // 8000,
                        "parallelism": f"dp{world}", "loss": round(loss, 5)},
             "roofline": roofline,

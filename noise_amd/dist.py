@@ -34,9 +34,15 @@ def make_grad_all_reduce(group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None
     world = dist.get_world_size(group)
+    via_host = dist.get_backend(group) == "gloo"      # rehearsal backend: stage device tensors through the host
 
     def all_reduce(flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if via_host and flat.is_cuda:
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world
     return all_reduce
 
