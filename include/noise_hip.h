@@ -56,11 +56,16 @@ int noise_conv_max_blocks(void);      /* slab rows a conv/bn kernel may write (s
 int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
                     int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, int transposed,
                     int B, int Hi, int Wi, int C, int sy, int sx, void* stream);
-/* g_in [B][Hi][Wi][C], dw (C,1,3,3); scratch >= noise_conv_max_blocks()*9*C floats */
+/* g_in [B][Hi][Wi][C], dw (C,1,3,3); scratch >= noise_conv_max_blocks()*11*C floats.
+ * Backward epilogue (all optional), shared by noise_dw3x3_bwd / noise_last_convT_bwd / noise_pw_bwd:
+ *   g_in += g_other (a second gradient of the same tensor, e.g. from a skip add); with epi_coef (the BatchNorm
+ *   coefficients of source a's producer) g_in is masked by that producer's ReLU6 (epi_relu6) and the producer's
+ *   BatchNorm-backward sums [sum dz | sum dz*xhat] are left in scratch for noise_bn_bwd_finalize
+ *   (here: *slab_rows rows of 11*C floats, sums in columns [9C, 11C)). */
 int noise_dw3x3_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,
                     int a_relu6, const float* b_y, const float* b_coef, int b_relu6, const float* w, float* g_in,
-                    float* dw, float* scratch, int transposed, int B, int Hi, int Wi, int C, int sy, int sx,
-                    void* stream);
+                    float* dw, float* scratch, const float* g_other, const float* epi_coef, int epi_relu6,
+                    int* slab_rows, int transposed, int B, int Hi, int Wi, int C, int sy, int sx, void* stream);
 /* first Conv2d 1->C (models.py:1151-1159) fused with normalise (:614-622) and left/top pad (:589) */
 int noise_first_conv_fwd(const float* logmag, const float* absmax, const float* w, float* out, float* stats_slab,
                          int* slab_rows, int B, int H, int W, int hp, int wp, float pad_value, int C, int sy,
@@ -74,11 +79,12 @@ int noise_last_convT_fwd(const float* a_y, const float* a_coef, int a_relu6, con
                          int b_relu6, const float* w, const float* bias, const float* logmag, const float* absmax,
                          float* enh, float* filt, int B, int Hi, int Wi, int C, int sy, int sx, int H, int W,
                          void* stream);
-/* scratch >= noise_conv_max_blocks()*10*C floats */
+/* scratch >= noise_conv_max_blocks()*12*C floats (rows of 12*C; producer sums in columns [10C, 12C)) */
 int noise_last_convT_bwd(const float* d_enh, const float* enh, const float* absmax, const float* a_y,
                          const float* a_coef, int a_relu6, const float* b_y, const float* b_coef, int b_relu6,
-                         const float* w, float* g_in, float* dw, float* dbias, float* scratch, int B, int Hi, int Wi,
-                         int C, int sy, int sx, int H, int W, void* stream);
+                         const float* w, float* g_in, float* dw, float* dbias, float* scratch, const float* g_other,
+                         const float* epi_coef, int epi_relu6, int* slab_rows, int B, int Hi, int Wi, int C, int sy,
+                         int sx, int H, int W, void* stream);
 /* pointwise convs (models.py:371-381, :395-396) as fp32 MFMA products: out [npix][N] = a [npix][K] x W[N][K]^T */
 int noise_pw_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
                  int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, long npix, int K, int N,
@@ -91,6 +97,14 @@ int noise_pw_wgrad(const float* dz, const float* y_out, const float* coef3, cons
                    int a_relu6, const float* b_y, const float* b_coef, int b_relu6, float* dw, float* scratch,
                    long npix, int Cout, int Cin, void* stream);
 
+int noise_pw_bwd_max_rows(int Cout, int Cin);   /* slab rows noise_pw_bwd may use for a Cout x Cin layer */
+/* fused dgrad + wgrad of a pointwise layer; stats_slab (with epi_coef) receives *slab_rows rows of 2*Cin floats;
+ * scratch >= noise_pw_bwd_max_rows(Cout, Cin)*Cout*Cin floats, stats_slab that many rows */
+int noise_pw_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,
+                 int a_relu6, const float* b_y, const float* b_coef, int b_relu6, const float* w, float* g_in, float* dw,
+                 float* scratch, const float* g_other, const float* epi_coef, int epi_relu6, float* stats_slab,
+                 int* slab_rows, long npix, int Cout, int Cin, void* stream);
+
 /* ---- BatchNorm2d in train / eval mode (every norm_layer of models.py:371-397, :1151-1159) ---- */
 int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, long count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
@@ -100,6 +114,10 @@ int noise_bn_coef_eval(int C, const float* gamma, const float* beta, const float
 /* dz may alias g1; scratch >= noise_conv_max_blocks()*2*C floats */
 int noise_bn_bwd(const float* g1, const float* g2, const float* y, const float* coef, int relu6, const float* gamma,
                  float* dz, float* dgamma, float* dbeta, float* coef3, float* scratch, long npix, int C, void* stream);
+
+/* the finalize half of noise_bn_bwd, for sums left by a consumer's backward epilogue */
+int noise_bn_bwd_finalize(const float* slab, int slab_rows, int row_stride, const float* coef, const float* gamma,
+                          float* dgamma, float* dbeta, float* coef3, long npix, int C, void* stream);
 
 /* ---- bottleneck attention block: models.py:207-225, :60-89, :27-37, :102-112, vad head :602 --- */
 int noise_attn_max_blocks(void);

@@ -99,15 +99,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nrows, int C, double count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nrows, int row_stride,
+                                                              int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef3) {
   __shared__ double red[256];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   const bool ok = c < C;
-  const double s1 = slab_column_sum(slab, nrows, 2 * C, c, ok, red);
-  const double s2 = slab_column_sum(slab, nrows, 2 * C, C + c, ok, red);
+  const double s1 = slab_column_sum(slab, nrows, row_stride, c, ok, red);
+  const double s2 = slab_column_sum(slab, nrows, row_stride, C + c, ok, red);
   if (threadIdx.x >= 32 || !ok) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
@@ -159,8 +160,21 @@ NOISE_EXPORT int noise_bn_bwd(const float* g1, const float* g2, const float* y, 
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float), st, g1, g2, y, coef,
                      relu6, C, npix, dz, scratch);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, st, scratch, grid, C, (double)npix, gamma,
-                     coef, dgamma, dbeta, coef3);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, C, (double)npix,
+                     gamma, coef, dgamma, dbeta, coef3);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/finalize");
+  return 0;
+}
+
+// Second half of noise_bn_bwd alone, for sums that a consumer's backward epilogue already left in `slab`
+// (slab_rows rows of row_stride floats, [sum dz(C) | sum dz*xhat(C)] starting at the given pointer).
+NOISE_EXPORT int noise_bn_bwd_finalize(const float* slab, int slab_rows, int row_stride, const float* coef,
+                                       const float* gamma, float* dgamma, float* dbeta, float* coef3, long npix, int C,
+                                       void* stream) {
+  NOISE_REQUIRE(slab && coef && gamma && dgamma && dbeta && coef3 && slab_rows > 0 && row_stride >= 2 * C && npix > 0,
+                "noise_bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, slab, slab_rows,
+                     row_stride, C, (double)npix, gamma, coef, dgamma, dbeta, coef3);
+  NOISE_CHECK_LAUNCH("noise_bn_bwd_finalize");
   return 0;
 }

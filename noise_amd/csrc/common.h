@@ -66,6 +66,19 @@ struct LazyGrad {
   const float* coef3;
 };
 
+// What a backward kernel does with the input gradient g it has just computed for source A:
+//   g += g_other (second gradient of the same tensor, e.g. the decoder's skip branch)     [optional]
+//   g  = g * [0 < scale*y_A + shift < 6]            (ReLU6 of the producer, when relu6)    [needs coef]
+//   partial sums of g and g*xhat_A go to stats_slab                                       [needs coef]
+// so that the producer's BatchNorm backward needs no pass of its own.  coef is the PRODUCER's
+// [scale|shift|mean|invstd|mean_lo]; all members may be null / 0.
+struct BwdEpilogue {
+  const float* g_other;
+  const float* coef;
+  int relu6;
+  float* stats_slab;
+};
+
 #ifdef __HIPCC__
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;

@@ -89,19 +89,20 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(LazySrc A, LazySrc Bsrc, co
 template <int GEOM>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
                                                      float* __restrict__ g_in, float* __restrict__ dw_slab,
-                                                     ConvDims d) {
+                                                     BwdEpilogue E, ConvDims d) {
   // d.Hi/Wi: the layer's INPUT size (destination of this gather); d.Ho/Wo: its output size (source of dy)
   extern __shared__ float red[];
   const int C = d.C, CG = C >> 2, PPB = 256 / CG;
   const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
   const bool active = pl < PPB;
-  float4 dwk[9];
+  float4 dwk[11];   // 9 taps + the two BatchNorm-backward sums of the producer (slots 9, 10)
 #pragma unroll
-  for (int k = 0; k < 9; ++k) dwk[k] = f4(0.f);
+  for (int k = 0; k < 11; ++k) dwk[k] = f4(0.f);
   if (active) {
     const int c = 4 * cg;
     const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
     const LazyGrad4 g = lazygrad4_init(G, C, c);
+    const Epi4 epi = epi4_init(E, C, c);
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
       const int r = pix / d.Wi;
       const int iy = r % d.Hi, bi = r / d.Hi;
       const size_t ioff = (size_t)pix * C + c;
-      float4 av = lazy4_at(a, ioff);
+      const float4 yraw = ld4(a.y + ioff);
+      float4 av = fma4(yraw, a.scale, a.shift);
+      if (a.act == ACT_RELU6) av = relu6_4(av);
       if (b.present) av = av + lazy4_at(b, ioff);
       float4 acc = f4(0.f);
 #pragma unroll
@@ -128,11 +131,12 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
           dwk[ky * 3 + kx] = fma4(dy, av, dwk[ky * 3 + kx]);
         }
       }
+      acc = epi4_apply(epi, acc, yraw, ioff, dwk[9], dwk[10]);
       if (g_in != nullptr) st4(g_in + ioff, acc);
     }
   }
-  // slab row layout: [k][C]  (the finalize kernel transposes to the (C,1,3,3) parameter layout)
-  block_channel_reduce<9>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 9 * C);
+  // slab row layout: [k][C] for the 9 taps (the reduce kernel transposes to (C,1,3,3)), then [sum dz | sum dz*xhat]
+  block_channel_reduce<11>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -349,16 +353,17 @@ __global__ __launch_bounds__(256) void last_convT_fwd_split_kernel(LazySrc A, La
 __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __restrict__ d_enh, const float* __restrict__ enh,
                                                              const float* __restrict__ absmax, LazySrc A, LazySrc Bsrc,
                                                              const float* __restrict__ w, float* __restrict__ g_in,
-                                                             float* __restrict__ dw_slab, LastDims d) {
+                                                             float* __restrict__ dw_slab, BwdEpilogue E, LastDims d) {
   extern __shared__ float red[];
   const int C = d.C, CG = C >> 2, PPB = 256 / CG;
   const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG;
-  float4 dwk[10];  // 9 taps + (channel group 0 only) the bias gradient in .x of slot 9
+  float4 dwk[12];  // 9 taps, bias gradient in .x of slot 9 (channel group 0 only), producer BN sums in 10, 11
 #pragma unroll
-  for (int k = 0; k < 10; ++k) dwk[k] = f4(0.f);
+  for (int k = 0; k < 12; ++k) dwk[k] = f4(0.f);
   if (pl < PPB) {
     const int c = 4 * cg;
     const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+    const Epi4 epi = epi4_init(E, C, c);
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
@@ -369,7 +374,9 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
       const int iy = r % d.Hi, bi = r / d.Hi;
       const float mx = absmax[bi] + 1e-6f;
       const size_t ioff = (size_t)pix * C + c;
-      float4 av = lazy4_at(a, ioff);
+      const float4 yraw = ld4(a.y + ioff);
+      float4 av = fma4(yraw, a.scale, a.shift);
+      if (a.act == ACT_RELU6) av = relu6_4(av);
       if (b.present) av = av + lazy4_at(b, ioff);
       float4 acc = f4(0.f);
 #pragma unroll
@@ -387,6 +394,7 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
           dwk[ky * 3 + kx] = fma4(f4(dy), av, dwk[ky * 3 + kx]);
         }
       }
+      acc = epi4_apply(epi, acc, yraw, ioff, dwk[10], dwk[11]);
       st4(g_in + ioff, acc);
     }
     // bias gradient: every output position is owned by exactly one (pixel lane, cg==0) visit below
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
       dwk[9].x = s;
     }
   }
-  block_channel_reduce<10>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 10 * C);
+  block_channel_reduce<12>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 12 * C);
 }
 
 // out[j] = sum_b slab[b][j]; optional transpose from [k][C] slab rows to the (C,k) parameter layout
@@ -470,10 +478,14 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
 }
 
 // Backward of noise_dw3x3_fwd.  (Hi,Wi) is the forward INPUT size.  Writes g_in (B,Hi,Wi,C) and dw (C,3,3).
-// scratch: at least noise_conv_max_blocks()*9*C floats.
+// Epilogue (all optional): g_in += g_other; with epi_coef (the BatchNorm coefficients of source a's producer)
+// g_in is masked by that producer's ReLU6 (epi_relu6) and the producer's BatchNorm-backward sums are left in
+// scratch: rows of 11*C floats, columns [9*C, 11*C) = [sum dz | sum dz*xhat]; *slab_rows receives the row count.
+// scratch: at least noise_conv_max_blocks()*11*C floats.
 NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y,
                                  const float* a_coef, int a_relu6, const float* b_y, const float* b_coef, int b_relu6,
-                                 const float* w, float* g_in, float* dw, float* scratch, int transposed, int B, int Hi,
+                                 const float* w, float* g_in, float* dw, float* scratch, const float* g_other,
+                                 const float* epi_coef, int epi_relu6, int* slab_rows, int transposed, int B, int Hi,
                                  int Wi, int C, int sy, int sx, void* stream) {
   if (check_c("noise_dw3x3_bwd", C)) return -1;
   NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "noise_dw3x3_bwd: empty input");
@@ -489,15 +501,17 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   if (check_size("noise_dw3x3_bwd", (long)B * d.Ho * d.Wo + (long)B * Hi * Wi, C)) return -1;
   const int grid = conv_grid((long)B * Hi * Wi, C);
   const int PPB = 256 / (C / 4);
-  const size_t smem = (size_t)PPB * 9 * C * sizeof(float);
+  const size_t smem = (size_t)PPB * 11 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
+  if (slab_rows) *slab_rows = grid;
   // the adjoint of a CONV gather is a CONVT gather and vice versa
   if (transposed)
-    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, d);
+    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
   else
-    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, d);
+    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
   return 0;
 }
@@ -563,10 +577,12 @@ NOISE_EXPORT int noise_last_convT_fwd(const float* a_y, const float* a_coef, int
   return 0;
 }
 
-// g_in (B,Hi,Wi,C), dw (C,1,3,3), dbias (1).  scratch: noise_conv_max_blocks()*10*C floats.
+// g_in (B,Hi,Wi,C), dw (C,1,3,3), dbias (1).  Epilogue as in noise_dw3x3_bwd; scratch rows are 12*C floats with
+// the producer sums in columns [10*C, 12*C).  scratch: noise_conv_max_blocks()*12*C floats.
 NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, const float* absmax, const float* a_y,
                                       const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
                                       int b_relu6, const float* w, float* g_in, float* dw, float* dbias, float* scratch,
+                                      const float* g_other, const float* epi_coef, int epi_relu6, int* slab_rows,
                                       int B, int Hi, int Wi, int C, int sy, int sx, int H, int W, void* stream) {
   if (check_c("noise_last_convT_bwd", C)) return -1;
   NOISE_REQUIRE(d_enh && enh && absmax && a_y && w && g_in && dw && dbias && scratch, "noise_last_convT_bwd: null pointer");
@@ -577,13 +593,15 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
   const int grid = conv_grid((long)B * Hi * Wi, C);
   const int PPB = 256 / (C / 4);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 10 * C * sizeof(float), st, d_enh, enh,
-                     absmax, A, Bs, w, g_in, scratch, d);
+  BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
+  if (slab_rows) *slab_rows = grid;
+  hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
+                     absmax, A, Bs, w, g_in, scratch, E, d);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(10 * C, 32)), dim3(256), 0, st, scratch, grid, 10 * C, 10 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 12 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd/reduce");
   // the bias gradient sits at slab column 9*C (slot 9, channel 0)
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, scratch + 9 * C, grid, 1, 10 * C, dbias, 0, 0, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, scratch + 9 * C, grid, 1, 12 * C, dbias, 0, 0, 0);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd/bias");
   return 0;
 }

@@ -14,6 +14,7 @@ __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 relu6_4(float4 v) { return make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w)); }
 
 // Per-thread view of one lazy source restricted to 4 consecutive channels c..c+3.
@@ -57,8 +58,6 @@ struct LazyGrad4 {
   bool affine;
 };
 
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-
 __device__ __forceinline__ LazyGrad4 lazygrad4_init(const LazyGrad& g, int C, int c) {
   LazyGrad4 r;
   r.dz = g.dz;
@@ -87,6 +86,50 @@ __device__ __forceinline__ float4 lazygrad4_at(const LazyGrad4& g, size_t off) {
 
 __device__ __forceinline__ float lazygrad1(float dz, float y, float s, float k1h, float k1l, float a2, float mh, float ml) {
   return fmaf(a2, (y - mh) - ml, s * ((dz - k1h) - k1l));
+}
+
+// Per-thread state of a BwdEpilogue restricted to 4 consecutive channels of the producer.
+struct Epi4 {
+  const float* g_other;
+  float4 scale, shift, mean, mlo, istd;
+  bool stats, relu6;
+};
+
+__device__ __forceinline__ Epi4 epi4_init(const BwdEpilogue& e, int C, int c) {
+  Epi4 r;
+  r.g_other = e.g_other;
+  r.stats = e.coef != nullptr;
+  r.relu6 = e.relu6 != 0;
+  r.scale = f4(1.f);
+  r.shift = r.mean = r.mlo = f4(0.f);
+  r.istd = f4(1.f);
+  if (r.stats) {
+    r.scale = ld4(e.coef + c);
+    r.shift = ld4(e.coef + C + c);
+    r.mean = ld4(e.coef + 2 * C + c);
+    r.istd = ld4(e.coef + 3 * C + c);
+    r.mlo = ld4(e.coef + 4 * C + c);
+  }
+  return r;
+}
+
+// Applies the epilogue to gradient g of the element whose raw producer output is yraw; accumulates the
+// two BatchNorm-backward sums.  Returns the value to store.
+__device__ __forceinline__ float4 epi4_apply(const Epi4& e, float4 g, float4 yraw, size_t off, float4& s1, float4& s2) {
+  if (e.g_other) g = g + ld4(e.g_other + off);
+  if (e.stats) {
+    if (e.relu6) {
+      const float4 v = fma4(yraw, e.scale, e.shift);
+      g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
+      g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
+      g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
+      g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
+    }
+    const float4 xh = sub4(sub4(yraw, e.mean), e.mlo) * e.istd;
+    s1 = s1 + g;
+    s2 = fma4(g, xh, s2);
+  }
+  return g;
 }
 
 // Gather geometry of a 3x3, pad-1 stencil along one axis.

@@ -240,6 +240,195 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, La
   for (int j = tid; j < N * K; j += 256) slab[(size_t)blockIdx.x * N * K + j] = lds[j];
 }
 
+// Fused backward of a pointwise layer: one pass over (dz, y_out) and the layer input computes
+//   g_in[p][ci] = sum_co dy[p][co] W[co][ci]     (then the BwdEpilogue: + g_other, producer ReLU6 mask, producer BN sums)
+//   dW[co][ci] += sum_p dy[p][co] a[p][ci]
+// KC = ceil(N/16) (N = Cout), MTI = ceil(K/16) (K = Cin).  64 pixels per workgroup iteration are staged in LDS
+// (dy with the lazy BatchNorm backward applied, a with the lazy activation applied); each wave owns 16 of them.
+template <int KC, int MTI>
+__global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bs, const float* __restrict__ W,
+                                                     float* __restrict__ g_in, BwdEpilogue E, float* __restrict__ dw_slab,
+                                                     long npix, int N, int K) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;       // dgrad view: pixel lane / k-quarter;  wgrad view: i = p, kq = q
+  constexpr int NP = KC * 16, KP = MTI * 16;
+  constexpr int pn = NP + 4, pk = KP + 4;
+  float* wfrag = lds;                            // [MTI][KC][64][4]
+  float* dys = wfrag + MTI * KC * 256;           // [64][pn]
+  float* as = dys + WG_TILE * pn;                // [64][pk]
+  float* ecf = as + WG_TILE * pk;                // [5][KP] producer BN coefficients for the epilogue
+  for (int idx = tid; idx < MTI * KC * 256; idx += 256) {
+    const int r = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+    const int jj = t % KC, m = t / KC;
+    const int ci = 16 * m + (l & 15), co = 16 * jj + 4 * (l >> 4) + r;
+    wfrag[idx] = (co < N && ci < K) ? W[(size_t)co * K + ci] : 0.f;
+  }
+  for (int k = tid; k < KP; k += 256) {
+    const bool in = k < K && E.coef != nullptr;
+    ecf[k] = in ? E.coef[k] : 1.f;
+    ecf[KP + k] = in ? E.coef[K + k] : 0.f;
+    ecf[2 * KP + k] = in ? E.coef[2 * K + k] : 0.f;
+    ecf[3 * KP + k] = in ? E.coef[3 * K + k] : 1.f;
+    ecf[4 * KP + k] = in ? E.coef[4 * K + k] : 0.f;
+  }
+  f32x4 acc[KC][MTI];
+#pragma unroll
+  for (int m = 0; m < KC; ++m)
+#pragma unroll
+    for (int n = 0; n < MTI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 s1[MTI], s2[MTI];
+#pragma unroll
+  for (int m = 0; m < MTI; ++m) s1[m] = s2[m] = f4(0.f);
+
+  const long ntiles = (npix + WG_TILE - 1) / WG_TILE;
+  const long iters = (ntiles + gridDim.x - 1) / gridDim.x;
+  for (long it = 0; it < iters; ++it) {
+    const long tile = (long)blockIdx.x + it * gridDim.x;
+    const long pix0 = tile * WG_TILE;
+    __syncthreads();
+    for (int e = tid; e < WG_TILE * (NP / 4); e += 256) {
+      const int pp = e / (NP / 4), c = (e - pp * (NP / 4)) * 4;
+      float4 v = f4(0.f);
+      if (tile < ntiles && pix0 + pp < npix && c < N) {
+        const size_t off = (size_t)(pix0 + pp) * N + c;
+        v = ld4(G.dz + off);
+        if (G.coef3) {
+          const float4 t1 = sub4(sub4(v, ld4(G.coef3 + N + c)), ld4(G.coef3 + 2 * N + c));
+          const float4 t2 = sub4(sub4(ld4(G.y + off), ld4(G.coef3 + 4 * N + c)), ld4(G.coef3 + 5 * N + c));
+          v = fma4(ld4(G.coef3 + 3 * N + c), t2, ld4(G.coef3 + c) * t1);
+        }
+      }
+      st4(dys + pp * pn + c, v);
+    }
+    for (int e = tid; e < WG_TILE * (KP / 4); e += 256) {
+      const int pp = e / (KP / 4), c = (e - pp * (KP / 4)) * 4;
+      float4 v = f4(0.f);
+      if (tile < ntiles && pix0 + pp < npix && c < K) {
+        const size_t off = (size_t)(pix0 + pp) * K + c;
+        v = ld4(A.y + off);
+        if (A.coef) v = fma4(v, ld4(A.coef + c), ld4(A.coef + K + c));
+        if (A.relu6) v = relu6_4(v);
+        if (Bs.y) {
+          float4 u = ld4(Bs.y + off);
+          if (Bs.coef) u = fma4(u, ld4(Bs.coef + c), ld4(Bs.coef + K + c));
+          if (Bs.relu6) u = relu6_4(u);
+          v = v + u;
+        }
+      }
+      st4(as + pp * pk + c, v);
+    }
+    __syncthreads();
+    // ---- dgrad for this wave's 16 pixels
+    if (g_in != nullptr) {
+      const long pix = pix0 + 16 * wave + p;
+      const bool valid = tile < ntiles && pix < npix;
+      float4 in[KC];
+#pragma unroll
+      for (int jj = 0; jj < KC; ++jj) in[jj] = ld4(dys + (16 * wave + p) * pn + 16 * jj + 4 * q);
+#pragma unroll
+      for (int m = 0; m < MTI; ++m) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) {
+          const float4 wa = ld4(wfrag + ((m * KC + jj) * 64 + lane) * 4);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, o, 0, 0, 0);
+        }
+        const int ci = 16 * m + 4 * q;
+        if (valid && ci < K) {
+          const size_t off = (size_t)pix * K + ci;
+          float4 g = make_float4(o[0], o[1], o[2], o[3]);
+          if (E.g_other) g = g + ld4(E.g_other + off);
+          if (E.coef) {
+            const float4 yraw = ld4(A.y + off);
+            if (E.relu6) {
+              const float4 v = fma4(yraw, ld4(ecf + ci), ld4(ecf + KP + ci));
+              g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
+              g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
+              g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
+              g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
+            }
+            const float4 xh = sub4(sub4(yraw, ld4(ecf + 2 * KP + ci)), ld4(ecf + 4 * KP + ci)) * ld4(ecf + 3 * KP + ci);
+            s1[m] = s1[m] + g;
+            s2[m] = fma4(g, xh, s2[m]);
+          }
+          st4(g_in + off, g);
+        }
+      }
+    }
+    // ---- wgrad: 4 k-steps of 4 pixels
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int pp = 16 * wave + 4 * s + q;
+      float dy[KC], av[MTI];
+#pragma unroll
+      for (int m = 0; m < KC; ++m) dy[m] = dys[pp * pn + 16 * m + p];
+#pragma unroll
+      for (int n = 0; n < MTI; ++n) av[n] = as[pp * pk + 16 * n + p];
+#pragma unroll
+      for (int m = 0; m < KC; ++m)
+#pragma unroll
+        for (int n = 0; n < MTI; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[m], av[n], acc[m][n], 0, 0, 0);
+    }
+  }
+
+  // ---- producer BN sums: reduce over the 16 pixel lanes, then over the waves
+  __syncthreads();
+  if (E.stats_slab != nullptr) {
+    float* red = lds;   // [4 waves][2][KP]
+#pragma unroll
+    for (int m = 0; m < MTI; ++m) {
+      float v[8] = {s1[m].x, s1[m].y, s1[m].z, s1[m].w, s2[m].x, s2[m].y, s2[m].z, s2[m].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v[e] += __shfl_xor(v[e], o, 64);
+      }
+      if (p == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[(wave * 2 + 0) * KP + 16 * m + 4 * q + e] = v[e];
+          red[(wave * 2 + 1) * KP + 16 * m + 4 * q + e] = v[4 + e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i2 = tid; i2 < 2 * K; i2 += 256) {
+      const int j = i2 / K, c = i2 - j * K;
+      float sum = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) sum += red[(wv * 2 + j) * KP + c];
+      E.stats_slab[(size_t)blockIdx.x * 2 * K + i2] = sum;
+    }
+    __syncthreads();
+  }
+  // ---- dW: D layout col = ci0 + (lane&15), rows = co0 + 4*(lane>>4) + reg; fold the four waves through LDS
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int m = 0; m < KC; ++m)
+#pragma unroll
+        for (int n = 0; n < MTI; ++n) {
+          const int ci = 16 * n + p;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = 16 * m + 4 * q + e;
+            if (co < N && ci < K) {
+              float* dst = lds + co * K + ci;
+              *dst = (wv == 0) ? acc[m][n][e] : *dst + acc[m][n][e];
+            }
+          }
+        }
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < N * K; j += 256) dw_slab[(size_t)blockIdx.x * N * K + j] = lds[j];
+}
+
 __global__ __launch_bounds__(256) void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols,
                                                              float* __restrict__ out) {
   __shared__ double red[256];
@@ -348,5 +537,56 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
   NOISE_CHECK_LAUNCH("noise_pw_wgrad");
   hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 32)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
   NOISE_CHECK_LAUNCH("noise_pw_wgrad/reduce");
+  return 0;
+}
+
+// Upper bound of workgroups (= slab rows) noise_pw_bwd uses for a Cout x Cin layer: enough to keep several
+// workgroups per CU in flight, while the dW slab stays below 16 MiB.
+NOISE_EXPORT int noise_pw_bwd_max_rows(int Cout, int Cin) {
+  long cap = (16L << 20) / ((long)Cout * Cin * 4);
+  if (cap < 256) cap = 256;
+  if (cap > 1024) cap = 1024;
+  return (int)cap;
+}
+
+// Fused backward of a pointwise layer (see pw_bwd_kernel): g_in (npix, Cin) and dw (Cout, Cin) from one pass.
+// Epilogue (optional): g_in += g_other; with epi_coef (BatchNorm coefficients of source a's producer) g_in is
+// masked by the producer's ReLU6 (epi_relu6) and stats_slab receives *slab_rows rows of [sum dz | sum dz*xhat]
+// (2*Cin floats each).  scratch: noise_pw_bwd_max_rows(Cout, Cin)*Cout*Cin floats; stats_slab: that many rows.
+NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y,
+                              const float* a_coef, int a_relu6, const float* b_y, const float* b_coef, int b_relu6,
+                              const float* w, float* g_in, float* dw, float* scratch, const float* g_other,
+                              const float* epi_coef, int epi_relu6, float* stats_slab, int* slab_rows, long npix,
+                              int Cout, int Cin, void* stream) {
+  NOISE_REQUIRE(dz && a_y && w && g_in && dw && scratch && npix > 0, "noise_pw_bwd: bad argument");
+  NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_pw_bwd: coef3 needs y_out");
+  NOISE_REQUIRE(epi_coef == nullptr || stats_slab != nullptr, "noise_pw_bwd: epi_coef needs stats_slab");
+  NOISE_REQUIRE(Cout % 4 == 0 && Cin % 4 == 0, "noise_pw_bwd: channel counts must be multiples of 4");
+  const int KC = (Cout + 15) / 16, MTI = (Cin + 15) / 16;
+  LazyGrad G{dz, y_out, coef3};
+  LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
+  BwdEpilogue E{g_other, epi_coef, epi_relu6, epi_coef ? stats_slab : nullptr};
+  const int grid = noise_grid(npix, WG_TILE, noise_pw_bwd_max_rows(Cout, Cin));
+  if (slab_rows) *slab_rows = grid;
+  size_t smem = (size_t)(MTI * KC * 256 + WG_TILE * (KC * 16 + 4) + WG_TILE * (MTI * 16 + 4) + 5 * MTI * 16) * sizeof(float);
+  if ((size_t)Cout * Cin * sizeof(float) > smem) smem = (size_t)Cout * Cin * sizeof(float);
+  NOISE_REQUIRE(smem <= 160 * 1024, "noise_pw_bwd: %dx%d layer needs %zu bytes of LDS", Cout, Cin, smem);
+  hipStream_t st = (hipStream_t)stream;
+  bool done = false;
+#define X(nt, mt)                                                                                                       \
+  if constexpr (mt * nt <= 48) {                                                                                        \
+    if (!done && KC == mt && MTI == nt) {                                                                               \
+      NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt>), smem);                                                                   \
+      hipLaunchKernelGGL((pw_bwd_kernel<mt, nt>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E, scratch, npix, \
+                         Cout, Cin);                                                                                    \
+      done = true;                                                                                                      \
+    }                                                                                                                   \
+  }
+  PW_CASES(X)
+#undef X
+  NOISE_REQUIRE(done, "noise_pw_bwd: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
+  NOISE_CHECK_LAUNCH("noise_pw_bwd");
+  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 32)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
+  NOISE_CHECK_LAUNCH("noise_pw_bwd/reduce");
   return 0;
 }

@@ -43,7 +43,7 @@ ATTN_DROPOUT = 0.1  # ScaledDotProductAttention default, never overridden by the
 class _Rec:
     """One convolution layer of the schedule and the buffers that belong to it."""
     __slots__ = ("name", "kind", "conv", "bn", "relu6", "C", "Cin", "B", "Hi", "Wi", "Ho", "Wo", "stride",
-                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "g1", "g2", "g_in")
+                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "dz", "g_in")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -165,10 +165,10 @@ class DenoiserPlan:
         self.enh = torch.empty(B, H, W, **f32)
         # ---- scratch shared by all layers
         maxC = max(r.C for r in self.recs)
-        maxw = max((r.C * r.Cin for r in self.recs if r.kind == "pw"), default=1)
+        maxw = max((r.C * r.Cin * ops.pw_bwd_max_rows(r.C, r.Cin) for r in self.recs if r.kind == "pw"), default=1)
         att_cols = max(2 * D * D + D * hd + 7 * D + 1, 3 * hd * D + 2 * D)
-        self.slab = torch.empty(max(ops.CONV_MAX_BLOCKS * 10 * maxC, ops.PW_WGRAD_MAX_BLOCKS * maxw,
-                                    ATTN_MAX_BLOCKS * att_cols), **f32)
+        self.slab = torch.empty(max(ops.CONV_MAX_BLOCKS * 12 * maxC, maxw, ATTN_MAX_BLOCKS * att_cols), **f32)
+        self.slab2 = torch.empty(1024 * 2 * maxC, **f32)
         self.att_grads = torch.empty(att_cols, **f32)
         self.bwd_ready = False
 
@@ -257,60 +257,60 @@ class DenoiserPlan:
     # -------------------------------------------------------------------------------- backward
     def backward(self, d_enh, d_vad, grad_of):
         """d_enh (B,H,W) = dL/d(enhanced log-magnitude), d_vad (B,) = dL/d(vad logit).
-        `grad_of(param)` returns the tensor that receives that parameter's gradient (overwritten)."""
+        `grad_of(param)` returns the tensor that receives that parameter's gradient (overwritten).
+
+        Every layer's backward kernel also finishes the BatchNorm backward of the layer that PRODUCED its input:
+        it adds the pending skip-branch gradient, applies the producer's ReLU6 mask and leaves the two per-channel
+        sums, so the only work left per BatchNorm is a tiny finalize kernel."""
         self.ensure_backward_buffers()
         net = self.net
         G = grad_of
-        for r in self.recs:
-            r.g1 = r.g2 = None
         by_y = {id(r.y): r for r in self.recs if r.y is not None}
+        pending_skip = {}      # id(rec) -> gradient w.r.t. that rec's activation coming from a decoder skip add
 
-        def route(src, g):
-            """register g as a gradient of the producer of lazy source `src`"""
-            if src is None:
-                return
-            prod = by_y.get(id(src[0]))
-            if prod is None:
-                return
-            if prod.g1 is None:
-                prod.g1 = g
-            else:
-                prod.g2 = g
+        def producer(src):
+            return by_y.get(id(src[0])) if src is not None else None
 
-        def bn_backward(r):
-            need_write = r.relu6 or r.g2 is not None
-            # a gradient buffer that is also someone's second gradient must stay intact: write in place only into g1
-            ops.bn_bwd(r.g1, r.g2, r.y, r.coef, r.relu6, r.bn.weight, r.g1 if need_write else None, G(r.bn.weight),
-                       G(r.bn.bias), r.coef3, self.slab, r.npix_out, r.C)
-            return (r.g1, r.y, r.coef3)
+        def epilogue_for(pa):
+            if pa is None:
+                return None, None
+            return pending_skip.pop(id(pa), None), (pa.coef, pa.relu6)
+
+        def finalize(pa, slab_view, rows, row_stride):
+            if pa is not None:
+                ops.bn_bwd_finalize(slab_view, rows, row_stride, pa.coef, pa.bn.weight, G(pa.bn.weight), G(pa.bn.bias),
+                                    pa.coef3, pa.npix_out, pa.C)
+
+        def done(r, pa, pb):
+            if pa is not None:
+                pa.dz = r.g_in
+            if pb is not None:
+                pending_skip[id(pb)] = r.g_in
 
         # ---- last layer
         last = self.dec[-1][0]
-        ops.last_convT_bwd(d_enh, self.enh, self.absmax, last.src_a, last.src_b, last.conv.weight, last.g_in,
-                           G(last.conv.weight), G(last.conv.bias), self.slab, last.B, last.Hi, last.Wi, last.Cin,
-                           last.stride, self.H, self.W)
-        # order matters: the skip (second) gradient of an encoder tensor is registered first as g1 only if no main
-        # consumer exists yet; main consumers of encoder tensors run later, so route skip grads into g2 explicitly.
-        route_main = route
-
-        def route_skip(src, g):
-            prod = by_y.get(id(src[0])) if src is not None else None
-            if prod is not None:
-                prod.g2 = g
-
-        route_main(last.src_a, last.g_in)
-        route_skip(last.src_b, last.g_in)
+        pa, pb = producer(last.src_a), producer(last.src_b)
+        g_other, epi = epilogue_for(pa)
+        C = last.Cin
+        rows = ops.last_convT_bwd(d_enh, self.enh, self.absmax, last.src_a, last.src_b, last.conv.weight, last.g_in,
+                                  G(last.conv.weight), G(last.conv.bias), self.slab, last.B, last.Hi, last.Wi, C,
+                                  last.stride, self.H, self.W, g_other, epi)
+        finalize(pa, self.slab[10 * C:], rows, 12 * C)
+        done(last, pa, pb)
 
         def layer_backward(r):
-            grad = bn_backward(r)
+            grad = (r.dz, r.y, r.coef3)
+            pa, pb = producer(r.src_a), producer(r.src_b)
+            g_other, epi = epilogue_for(pa)
             if r.kind == "pw":
-                ops.pw_wgrad(grad, r.src_a, r.src_b, G(r.conv.weight), self.slab, r.npix_in, r.C, r.Cin)
-                ops.pw_dgrad(grad, r.conv.weight, None, r.g_in, r.npix_in, r.C, r.Cin)
+                rows = ops.pw_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, G(r.conv.weight), self.slab, r.npix_in,
+                                  r.C, r.Cin, g_other, epi, self.slab2)
+                finalize(pa, self.slab2, rows, 2 * r.Cin)
             else:
-                ops.dw3x3_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, G(r.conv.weight), self.slab, r.transposed,
-                              r.B, r.Hi, r.Wi, r.C, r.stride)
-            route_main(r.src_a, r.g_in)
-            route_skip(r.src_b, r.g_in)
+                rows = ops.dw3x3_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, G(r.conv.weight), self.slab,
+                                     r.transposed, r.B, r.Hi, r.Wi, r.C, r.stride, g_other, epi)
+                finalize(pa, self.slab[9 * r.C:], rows, 11 * r.C)
+            done(r, pa, pb)
 
         for layers in reversed(self.dec[:-1]):
             for r in reversed(layers):
@@ -347,13 +347,19 @@ class DenoiserPlan:
                      (att.layer_norm.weight, D), (att.layer_norm.bias, D)):
             G(t).view(-1).copy_(g[o:o + n])
             o += n
+        # the bottleneck tensor gets dL/dx0 from the attention block plus the skip gradient of decoder.0: this one
+        # BatchNorm backward keeps its own (small) reduction pass
         bott = self.enc[-1][-1]
-        bott.g1 = self.d_x0.view(bott.B, bott.Ho, bott.Wo, bott.C)   # (its g2 is the skip gradient from decoder.0)
+        d_x0 = self.d_x0.view(bott.B, bott.Ho, bott.Wo, bott.C)
+        skip = pending_skip.pop(id(bott), None)
+        ops.bn_bwd(d_x0, skip, bott.y, bott.coef, bott.relu6, bott.bn.weight, d_x0 if (bott.relu6 or skip is not None)
+                   else None, G(bott.bn.weight), G(bott.bn.bias), bott.coef3, self.slab, bott.npix_out, bott.C)
+        bott.dz = d_x0
         # ---- encoder
         for layers in reversed(self.enc[1:]):
             for r in reversed(layers):
                 layer_backward(r)
         r0 = self.enc[0][0]
-        grad = bn_backward(r0)
-        ops.first_conv_wgrad(grad, self.logmag, self.absmax, G(r0.conv.weight), self.slab, self.B, self.H, self.W, self.hp,
-                             self.wp, net.pad_value, r0.C, r0.stride)
+        ops.first_conv_wgrad((r0.dz, r0.y, r0.coef3), self.logmag, self.absmax, G(r0.conv.weight), self.slab, self.B,
+                             self.H, self.W, self.hp, self.wp, net.pad_value, r0.C, r0.stride)
+        assert not pending_skip, "unconsumed skip gradients"

@@ -16,22 +16,30 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 _lib.register({
     "noise_dw3x3_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "noise_dw3x3_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_dw3x3_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_first_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "noise_first_conv_wgrad": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "noise_last_convT_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "noise_last_convT_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_last_convT_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_bn_finalize_fwd": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P, _P],
     "noise_bn_coef_eval": [_I, _P, _P, _P, _P, _F, _P, _P],
     "noise_bn_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "noise_pw_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
     "noise_pw_dgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "noise_pw_wgrad": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _I, _I, _P],
+    "noise_pw_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
+    "noise_bn_bwd_finalize": [_P, _I, _I, _P, _P, _P, _P, _P, _L, _I, _P],
 })
 _lib.lib.noise_conv_max_blocks.restype = ctypes.c_int
 _lib.lib.noise_pw_wgrad_max_blocks.restype = ctypes.c_int
 CONV_MAX_BLOCKS = _lib.lib.noise_conv_max_blocks()
 PW_WGRAD_MAX_BLOCKS = _lib.lib.noise_pw_wgrad_max_blocks()
+_lib.lib.noise_pw_bwd_max_rows.restype = ctypes.c_int
+_lib.lib.noise_pw_bwd_max_rows.argtypes = [ctypes.c_int, ctypes.c_int]
+
+
+def pw_bwd_max_rows(Cout, Cin):
+    return _lib.lib.noise_pw_bwd_max_rows(Cout, Cin)
 
 NONE = (None, None, 0)
 
@@ -58,11 +66,21 @@ def dw3x3_fwd(a, b, w, out, slab, transposed, B, Hi, Wi, C, stride):
     return rows.value
 
 
-def dw3x3_bwd(grad, a, b, w, g_in, dw, scratch, transposed, B, Hi, Wi, C, stride):
+def _epi(epi):
+    coef, relu6 = epi if epi is not None else (None, 0)
+    return ptr(coef), int(bool(relu6))
+
+
+def dw3x3_bwd(grad, a, b, w, g_in, dw, scratch, transposed, B, Hi, Wi, C, stride, g_other=None, epi=None):
+    """epi = (producer coef, producer relu6) or None.  Returns the slab row count; with epi the producer's
+    BatchNorm-backward sums are in scratch columns [9C, 11C) of rows that are 11*C floats long."""
     dz, y, coef3 = grad
+    rows = ctypes.c_int(0)
     _lib.call("noise_dw3x3_bwd", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(w), ptr(g_in), ptr(dw),
-              ptr(scratch), int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream(),
-              nbytes=4 * C * (B * Hi * Wi * (_nsrc(b) + 1)) + dz.numel() * 4 * (2 if coef3 is not None else 1))
+              ptr(scratch), ptr(g_other), *_epi(epi), ctypes.byref(rows), int(transposed), B, Hi, Wi, C, stride[0],
+              stride[1], _lib.stream(),
+              nbytes=4 * C * (B * Hi * Wi * (_nsrc(b) + 1 + (g_other is not None))) + dz.numel() * 4 * (2 if coef3 is not None else 1))
+    return rows.value
 
 
 def first_conv_fwd(logmag, absmax, w, out, slab, B, H, W, hp, wp, pad_value, C, stride):
@@ -86,10 +104,15 @@ def last_convT_fwd(a, b, w, bias, logmag, absmax, enh, filt, B, Hi, Wi, C, strid
               nbytes=4 * (B * Hi * Wi * C * _nsrc(b) + 2 * B * H * W))
 
 
-def last_convT_bwd(d_enh, enh, absmax, a, b, w, g_in, dw, dbias, scratch, B, Hi, Wi, C, stride, H, W):
+def last_convT_bwd(d_enh, enh, absmax, a, b, w, g_in, dw, dbias, scratch, B, Hi, Wi, C, stride, H, W, g_other=None,
+                   epi=None):
+    """Scratch rows are 12*C floats; with epi the producer sums are in columns [10C, 12C).  Returns the row count."""
+    rows = ctypes.c_int(0)
     _lib.call("noise_last_convT_bwd", ptr(d_enh), ptr(enh), ptr(absmax), *_src(a), *_src(b), ptr(w), ptr(g_in),
-              ptr(dw), ptr(dbias), ptr(scratch), B, Hi, Wi, C, stride[0], stride[1], H, W, _lib.stream(),
+              ptr(dw), ptr(dbias), ptr(scratch), ptr(g_other), *_epi(epi), ctypes.byref(rows), B, Hi, Wi, C, stride[0],
+              stride[1], H, W, _lib.stream(),
               nbytes=4 * (B * Hi * Wi * C * (_nsrc(b) + 1) + 2 * B * H * W))
+    return rows.value
 
 
 def bn_finalize_fwd(slab, rows, C, count, gamma, beta, running_mean, running_var, nbt, coef, momentum=0.1, eps=1e-5):
@@ -125,3 +148,18 @@ def pw_wgrad(grad, a, b, dw, scratch, npix, Cout, Cin):
     dz, y, coef3 = grad
     _lib.call("noise_pw_wgrad", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(dw), ptr(scratch), npix, Cout,
               Cin, _lib.stream(), nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin * _nsrc(b)))
+
+
+def pw_bwd(grad, a, b, w, g_in, dw, scratch, npix, Cout, Cin, g_other=None, epi=None, stats_slab=None):
+    """Fused dgrad + wgrad (+ producer BatchNorm-backward sums into stats_slab when epi is given).  Returns rows."""
+    dz, y, coef3 = grad
+    rows = ctypes.c_int(0)
+    _lib.call("noise_pw_bwd", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(w), ptr(g_in), ptr(dw), ptr(scratch),
+              ptr(g_other), *_epi(epi), ptr(stats_slab), ctypes.byref(rows), npix, Cout, Cin, _lib.stream(),
+              nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin * (_nsrc(b) + 1 + (g_other is not None))))
+    return rows.value
+
+
+def bn_bwd_finalize(slab, rows, row_stride, coef, gamma, dgamma, dbeta, coef3, npix, C):
+    _lib.call("noise_bn_bwd_finalize", ptr(slab), rows, row_stride, ptr(coef), ptr(gamma), ptr(dgamma), ptr(dbeta),
+              ptr(coef3), npix, C, _lib.stream())

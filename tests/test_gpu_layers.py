@@ -113,11 +113,29 @@ def test_depthwise(dev, C, stride, transposed, two_src, shape):
     ref.backward(dy)
     g_in = torch.empty(B, Hi, Wi, C, device=dev)
     dw = torch.empty(C, 1, 3, 3, device=dev)
-    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 10 * C, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 12 * C, device=dev)
     ops.dw3x3_bwd((nhwc(dz).to(dev), out, c3.to(dev)), a_src, b_src, w.detach().to(dev), g_in, dw, scratch,
                   transposed, B, Hi, Wi, C, stride)
     close(nchw(g_in), a_in.grad, msg="dgrad")
     close(dw, w.grad, 1e-4, "wgrad")
+    # fused epilogue: + second gradient, producer ReLU6 mask, producer BatchNorm-backward sums
+    other = torch.randn(B, C, Hi, Wi, generator=g)
+    relu_a = not two_src
+    rows = ops.dw3x3_bwd((nhwc(dz).to(dev), out, c3.to(dev)), a_src, b_src, w.detach().to(dev), g_in, dw, scratch,
+                         transposed, B, Hi, Wi, C, stride, g_other=nhwc(other).to(dev), epi=(ca.to(dev), relu_a))
+    check_epilogue(g_in, scratch, rows, 11 * C, 9 * C, a_in.grad + other, ya, ca, relu_a, C)
+    close(dw, w.grad, 1e-4, "wgrad (epilogue run)")
+
+
+def check_epilogue(g_in, scratch, rows, row_stride, col0, g_ref_nchw, ya_nchw, ca, relu_a, C):
+    v = ya_nchw * ca[:C].view(1, C, 1, 1) + ca[C:2 * C].view(1, C, 1, 1)
+    mask = ((v > 0) & (v < 6)).float() if relu_a else torch.ones_like(v)
+    dz_ref = g_ref_nchw * mask
+    xh = (ya_nchw - ca[2 * C:3 * C].view(1, C, 1, 1)) * ca[3 * C:4 * C].view(1, C, 1, 1)
+    close(nchw(g_in), dz_ref, msg="epilogue dz")
+    sl = scratch[: rows * row_stride].view(rows, row_stride)[:, col0:col0 + 2 * C].double().sum(0).cpu()
+    close(sl[:C], dz_ref.double().sum((0, 2, 3)), 1e-4, "epilogue sum dz")
+    close(sl[C:], (dz_ref.double() * xh.double()).sum((0, 2, 3)), 1e-4, "epilogue sum dz*xhat")
 
 
 @pytest.mark.parametrize("K,N,npix,two_src", [
@@ -166,12 +184,28 @@ def test_pointwise(dev, K, N, npix, two_src):
     ops.pw_dgrad(grad, w.detach().to(dev), None, g_in, npix, N, K)
     close(g_in, a_in.grad, msg="dgrad")
     dw = torch.empty(N, K, device=dev)
-    scratch = torch.empty(ops.PW_WGRAD_MAX_BLOCKS * N * K, device=dev)
+    scratch = torch.empty(ops.pw_bwd_max_rows(N, K) * N * K, device=dev)
     ops.pw_wgrad(grad, a_src, b_src, dw, scratch, npix, N, K)
     close(dw, w.grad, 1e-4, "wgrad")
     # plain (coefficient-free) gradient path
     ops.pw_dgrad((dz.to(dev), None, None), w.detach().to(dev), None, g_in, npix, N, K)
     close(g_in, dz @ w.detach(), msg="dgrad plain")
+    # fused backward: dgrad + wgrad + epilogue in one pass
+    dw.zero_()
+    stats = torch.zeros(ops.pw_bwd_max_rows(N, K) * 2 * K, device=dev)
+    rows = ops.pw_bwd(grad, a_src, b_src, w.detach().to(dev), g_in, dw, scratch, npix, N, K, g_other=other.to(dev),
+                      epi=(ca.to(dev), relu_a), stats_slab=stats)
+    close(dw, w.grad, 1e-4, "fused wgrad")
+    v = ya * ca[:K] + ca[K:2 * K]
+    mask = ((v > 0) & (v < 6)).float() if relu_a else torch.ones_like(v)
+    dz_ref = (a_in.grad + other) * mask
+    close(g_in, dz_ref, msg="fused dgrad + epilogue")
+    xh = (ya - ca[2 * K:3 * K]) * ca[3 * K:4 * K]
+    sl = stats[: rows * 2 * K].view(rows, 2 * K).double().sum(0).cpu()
+    close(sl[:K], dz_ref.double().sum(0), 1e-4, "fused sum dz")
+    close(sl[K:], (dz_ref.double() * xh.double()).sum(0), 1e-4, "fused sum dz*xhat")
+    ops.pw_bwd(grad, a_src, b_src, w.detach().to(dev), g_in, dw, scratch, npix, N, K)
+    close(g_in, a_in.grad, msg="fused dgrad, no epilogue")
 
 
 @pytest.mark.parametrize("B,H,W,hp,wp", [(2, 161, 51, 0, 14), (1, 33, 20, 3, 5), (3, 17, 17, 0, 0)])
@@ -195,7 +229,7 @@ def test_first_conv(dev, B, H, W, hp, wp):
     dz = torch.randn(ref.shape, generator=g)
     ref.backward(dz)
     dw = torch.empty(C, 1, 3, 3, device=dev)
-    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 10 * C, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 12 * C, device=dev)
     ops.first_conv_wgrad((nhwc(dz).to(dev), None, None), lm_d, mx_d, dw, scratch, B, H, W, hp, wp, -1.0, C, stride)
     close(dw, w.grad, 1e-4, "wgrad")
 
@@ -227,12 +261,16 @@ def test_last_convT(dev, B, Hi, Wi, H, W):
     g_in = torch.empty(B, Hi, Wi, C, device=dev)
     dw = torch.empty(C, 1, 3, 3, device=dev)
     db = torch.empty(1, device=dev)
-    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 10 * C, device=dev)
+    scratch = torch.empty(ops.CONV_MAX_BLOCKS * 12 * C, device=dev)
     ops.last_convT_bwd(d_enh[:, 0].contiguous().to(dev), enh, mx_d, a_src, b_src, w.detach().to(dev), g_in, dw, db, scratch,
                        B, Hi, Wi, C, stride, H, W)
     close(nchw(g_in), a_in.grad, msg="dgrad")
     close(dw, w.grad, 1e-4, "wgrad")
     close(db, bias.grad, 1e-4, "bias grad")
+    rows = ops.last_convT_bwd(d_enh[:, 0].contiguous().to(dev), enh, mx_d, a_src, b_src, w.detach().to(dev), g_in, dw, db,
+                              scratch, B, Hi, Wi, C, stride, H, W, epi=(ca.to(dev), False))
+    check_epilogue(g_in, scratch, rows, 12 * C, 10 * C, a_in.grad, ya, ca, False, C)
+    close(db, bias.grad, 1e-4, "bias grad (epilogue run)")
 
 
 @pytest.mark.parametrize("C,relu6,two", [(32, True, True), (48, True, False), (24, False, True), (192, True, False)])
