@@ -134,6 +134,11 @@ def main():
         for name, (ms, nb, n) in rows:
             print(f"{name:28s} {ms / args.steps:9.3f} ms/step {100 * ms / total_ms:5.1f}%  {n // args.steps:4d} calls  "
                   f"{nb / 1e6 / max(ms, 1e-9):9.1f} GB/s", file=sys.stderr)
+        per_step = len(prof) // args.steps
+        for i, (name, nbytes, e0, e1) in enumerate(prof[:per_step]):    # every launch of the first timed step
+            ms = e0.elapsed_time(e1)
+            print(f"  #{i:3d} {name:26s} {ms:7.3f} ms {nbytes / 1e6:9.1f} MB {nbytes / 1e6 / max(ms, 1e-9):8.1f} GB/s",
+                  file=sys.stderr)
     dom, (dms, dbytes, dn) = rows[0]
     achieved = dbytes / 1e6 / dms  # bytes / ms -> GB/s
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

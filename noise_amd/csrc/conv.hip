@@ -16,6 +16,17 @@ struct ConvDims {
   int B, Hi, Wi, Ho, Wo, C, sy, sx;
 };
 
+// Pixel range [start, end) of this workgroup: contiguous chunks (a multiple of the PPB pixels one pass covers),
+// so the rows a 3x3 stencil shares between neighbouring pixels are re-read by the same CU a few passes
+// later (from its L1 / its XCD's L2) instead of by workgroups on other XCDs.
+__device__ __forceinline__ void pixel_chunk(int npix, int PPB, int& start, int& end) {
+  int chunk = (npix + (int)gridDim.x - 1) / (int)gridDim.x;
+  chunk = (chunk + PPB - 1) / PPB * PPB;
+  const long s0 = (long)blockIdx.x * chunk;
+  start = s0 < npix ? (int)s0 : npix;
+  end = s0 + chunk < npix ? (int)(s0 + chunk) : npix;
+}
+
 // Reduce per-thread float4 partials over the pixel lanes of a workgroup and write one row of the
 // slab: slab[block][j*C + c] for j < NV.  Threads are laid out tid = pl*CG + cg.
 template <int NV>
@@ -36,7 +47,13 @@ __device__ __forceinline__ void block_channel_reduce(const float4 (&v)[NV], int 
   }
 }
 
+}  // namespace
+#include "stencil_walk.h"
+namespace {
+
 // ------------------------------------------------------------------------------------------------
+// Generic one-thread-per-pixel kernels: any mix of strides 1 and 2 (the column walkers above take the
+// equal-stride layers, which are all the reference network has).
 // depthwise forward: out[o][c] = sum_k in[src(o,k)][c] * w[c][k]
 template <int GEOM>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
@@ -52,8 +69,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(LazySrc A, LazySrc Bsrc, co
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const int npix = d.B * d.Ho * d.Wo;
-    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+    int p0, p1;
+    pixel_chunk(d.B * d.Ho * d.Wo, PPB, p0, p1);
+    for (int pix = p0 + pl; pix < p1; pix += PPB) {
       const int ox = pix % d.Wo;
       const int r = pix / d.Wo;
       const int oy = r % d.Ho, bi = r / d.Ho;
@@ -106,8 +124,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const int npix = d.B * d.Hi * d.Wi;
-    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+    int p0, p1;
+    pixel_chunk(d.B * d.Hi * d.Wi, PPB, p0, p1);
+    for (int pix = p0 + pl; pix < p1; pix += PPB) {
       const int ix = pix % d.Wi;
       const int r = pix / d.Wi;
       const int iy = r % d.Hi, bi = r / d.Hi;
@@ -167,8 +186,9 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const int npix = d.B * d.Ho * d.Wo;
-    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+    int p0, p1;
+    pixel_chunk(d.B * d.Ho * d.Wo, PPB, p0, p1);
+    for (int pix = p0 + pl; pix < p1; pix += PPB) {
       const int ox = pix % d.Wo;
       const int r = pix / d.Wo;
       const int oy = r % d.Ho, bi = r / d.Ho;
@@ -205,8 +225,9 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(LazyGrad G, const
   if (pl < PPB) {
     const int c = 4 * cg;
     const LazyGrad4 g = lazygrad4_init(G, C, c);
-    const int npix = d.B * d.Ho * d.Wo;
-    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+    int p0, p1;
+    pixel_chunk(d.B * d.Ho * d.Wo, PPB, p0, p1);
+    for (int pix = p0 + pl; pix < p1; pix += PPB) {
       const int ox = pix % d.Wo;
       const int r = pix / d.Wo;
       const int oy = r % d.Ho, bi = r / d.Ho;
@@ -248,8 +269,9 @@ __global__ __launch_bounds__(256) void last_convT_fwd_kernel(LazySrc A, LazySrc 
     cf[3 * C + i] = (Bsrc.y && Bsrc.coef) ? Bsrc.coef[C + i] : 0.f;
   }
   __syncthreads();
-  const int npix = d.B * d.H * d.W;
-  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += gridDim.x * blockDim.x) {
+  int p0, p1;
+  pixel_chunk(d.B * d.H * d.W, blockDim.x, p0, p1);
+  for (int pix = p0 + threadIdx.x; pix < p1; pix += blockDim.x) {
     const int ox = pix % d.W;
     const int r = pix / d.W;
     const int oy = r % d.H, bi = r / d.H;
@@ -304,11 +326,11 @@ __global__ __launch_bounds__(256) void last_convT_fwd_split_kernel(LazySrc A, La
 #pragma unroll
   for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
   const float bv = bias[0];
-  const int npix = d.B * d.H * d.W;
-  const int iters = (npix + gridDim.x * PPB - 1) / (gridDim.x * PPB);   // uniform: the shuffles need whole pixel groups
-  for (int it = 0; it < iters; ++it) {
-    const int pix = (it * gridDim.x + blockIdx.x) * PPB + pl;
-    const bool valid = pix < npix;
+  int p0, p1;
+  pixel_chunk(d.B * d.H * d.W, PPB, p0, p1);
+  for (int base = p0; base < p1; base += PPB) {   // uniform trip count: the shuffles need whole pixel groups
+    const int pix = base + pl;
+    const bool valid = pix < p1;
     float acc = 0.f;
     int bi = 0;
     if (valid) {
@@ -367,8 +389,9 @@ __global__ __launch_bounds__(256) void last_convT_bwd_kernel(const float* __rest
     float4 wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = make_float4(w[(c + 0) * 9 + k], w[(c + 1) * 9 + k], w[(c + 2) * 9 + k], w[(c + 3) * 9 + k]);
-    const int npix = d.B * d.Hi * d.Wi;
-    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+    int p0, p1;
+    pixel_chunk(d.B * d.Hi * d.Wi, PPB, p0, p1);
+    for (int pix = p0 + pl; pix < p1; pix += PPB) {
       const int ix = pix % d.Wi;
       const int r = pix / d.Wi;
       const int iy = r % d.Hi, bi = r / d.Hi;
@@ -448,7 +471,7 @@ int check_c(const char* who, int C) {
 
 }  // namespace
 
-NOISE_EXPORT int noise_conv_max_blocks(void) { return 1024; }
+NOISE_EXPORT int noise_conv_max_blocks(void) { return 2048; }
 
 // transposed = 0: Conv2d, 1: ConvTranspose2d (both k3, p1, groups=C, no bias)
 NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y,
@@ -465,9 +488,28 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
   d.Wo = transposed ? (Wi - 1) * sx + 1 : (Wi - 1) / sx + 1;
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   if (check_size("noise_dw3x3_fwd", (long)B * d.Ho * d.Wo + (long)B * Hi * Wi, C)) return -1;
-  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
   const int PPB = 256 / (C / 4);
   const size_t smem = (size_t)PPB * 2 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (sy == sx) {
+    WalkDims wd{B, Hi, Wi, d.Ho, d.Wo, C, 0, 0, 0, 0};
+    int grid;
+    const bool cell = transposed && sy == 2;
+    wd.wown = cell ? Wi : d.Wo;
+    walk_plan(wd, cell ? Hi : d.Ho, noise_conv_max_blocks(), grid);
+    if (slab_rows) *slab_rows = grid;
+    if (cell)
+      hipLaunchKernelGGL(walk_cell_fwd_kernel, dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+    else if (transposed)
+      hipLaunchKernelGGL((walk_gather_fwd_kernel<1, true>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+    else if (sy == 1)
+      hipLaunchKernelGGL((walk_gather_fwd_kernel<1, false>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+    else
+      hipLaunchKernelGGL((walk_gather_fwd_kernel<2, false>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+    NOISE_CHECK_LAUNCH("noise_dw3x3_fwd");
+    return 0;
+  }
+  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
   if (slab_rows) *slab_rows = grid;
   if (transposed)
     hipLaunchKernelGGL(dw_fwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, (hipStream_t)stream, A, Bs, w, out, stats_slab, d);
@@ -499,17 +541,34 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   LazyGrad G{dz, y_out, coef3};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   if (check_size("noise_dw3x3_bwd", (long)B * d.Ho * d.Wo + (long)B * Hi * Wi, C)) return -1;
-  const int grid = conv_grid((long)B * Hi * Wi, C);
   const int PPB = 256 / (C / 4);
   const size_t smem = (size_t)PPB * 11 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
+  int grid;
+  if (sy == sx) {
+    // source of the walk = dy (the layer's output size), destination = the layer's input
+    WalkDims wd{B, d.Ho, d.Wo, Hi, Wi, C, 0, 0, 0, 0};
+    const bool cell = !transposed && sy == 2;
+    wd.wown = cell ? d.Wo : Wi;
+    walk_plan(wd, cell ? d.Ho : Hi, noise_conv_max_blocks(), grid);
+    if (cell)
+      hipLaunchKernelGGL(walk_cell_bwd_kernel, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+    else if (!transposed)
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<1, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+    else if (sy == 1)
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<1, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+    else
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+  } else {
+    grid = conv_grid((long)B * Hi * Wi, C);
+    // the adjoint of a CONV gather is a CONVT gather and vice versa
+    if (transposed)
+      hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
+    else
+      hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
+  }
   if (slab_rows) *slab_rows = grid;
-  // the adjoint of a CONV gather is a CONVT gather and vice versa
-  if (transposed)
-    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
-  else
-    hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONVT>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");

@@ -1,0 +1,384 @@
+// Column-walking 3x3 depthwise stencils (NHWC fp32, equal stride 1 or 2 in both axes), gfx950.
+//
+// A thread owns one column of one clip (or of one band of rows of it) for 4 consecutive channels and walks
+// down the rows, keeping the rows the stencil shares between consecutive steps in registers.  Compared with
+// one thread per output pixel this loads every source element 3x (stride 1), 1.5x (stride 2) or 1x
+// (transposed stride 2) instead of 9x / 2.25x, evaluates the lazy BatchNorm(+ReLU6) or BatchNorm-backward
+// expression of each loaded element once, and has no divergent taps.
+//
+// Two geometries cover every 3x3 / pad 1 depthwise layer of the U-Net and its adjoints:
+//   gather<S>:  dst[o] = sum_k src[o*S - 1 + k] * w[k]                      (walks dst rows)
+//   cell     :  dst[o] = sum_k src[(o + 1 - k) / 2] * w[k], (o+1-k) even     (walks src rows; 2x2 dst per step)
+//
+//   layer (train/models.py)                  forward            backward (dgrad + wgrad)
+//   Conv2d s1           :385-393             gather<1>          gather<1>, taps flipped, on dy
+//   Conv2d s2           :385-393             gather<2>          cell on dy
+//   ConvTranspose2d s1  :299-345             gather<1> flipped  gather<1> on dy
+//   ConvTranspose2d s2  :299-345             cell               gather<2> on dy
+// (flipped: tap k uses w[8-k]; the weight gradient is written back with the same permutation.)
+#pragma once
+#include "lazy.h"
+
+namespace {
+
+struct WalkDims {
+  int B, Hs, Ws;   // source tensor (B, Hs, Ws, C)
+  int Hd, Wd;      // destination tensor (B, Hd, Wd, C)
+  int C;
+  int wown;        // columns owned by threads: Wd (gather) or Ws (cell)
+  int nb, bh;      // bands per clip and walked rows per band (dst rows for gather, src rows for cell)
+  int ngroups;     // number of groups of PPB = 256 / (C/4) column slots
+};
+
+__device__ __forceinline__ void load_taps(const float* __restrict__ w, int c, bool flip, float4 (&wk)[9]) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int kk = flip ? 8 - k : k;
+    wk[k] = make_float4(w[(c + 0) * 9 + kk], w[(c + 1) * 9 + kk], w[(c + 2) * 9 + kk], w[(c + 3) * 9 + kk]);
+  }
+}
+
+// Decode a column slot: clip, band rows [r0, r1) and owned column.
+__device__ __forceinline__ bool walk_slot(const WalkDims& d, int slot, int nrows, int& bi, int& r0, int& r1, int& col) {
+  if (slot >= d.B * d.nb * d.wown) return false;
+  col = slot % d.wown;
+  const int u = slot / d.wown;
+  const int band = u % d.nb;
+  bi = u / d.nb;
+  r0 = band * d.bh;
+  r1 = r0 + d.bh < nrows ? r0 + d.bh : nrows;
+  return r0 < r1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, gather geometry
+template <int S, bool FLIP>
+__global__ __launch_bounds__(256) void walk_gather_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                              float* __restrict__ out, float* __restrict__ slab,
+                                                              WalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (pl < PPB) {
+    const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+    float4 wk[9];
+    load_taps(w, c, FLIP, wk);
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      int bi, r0, r1, ox;
+      if (!walk_slot(d, g * PPB + pl, d.Hd, bi, r0, r1, ox)) continue;
+      const int ix0 = ox * S - 1;
+      const bool v0 = ix0 >= 0, v1 = ix0 + 1 < d.Ws, v2 = ix0 + 2 < d.Ws;
+      const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
+      auto load_row = [&](int iy, float4(&r)[3]) {
+        r[0] = r[1] = r[2] = f4(0.f);
+        if (iy < 0 || iy >= d.Hs) return;
+        const size_t off = clip + ((size_t)iy * d.Ws + ix0) * C;   // ix0 = -1 is never dereferenced
+        if (v0) r[0] = b.present ? lazy4_at(a, off) + lazy4_at(b, off) : lazy4_at(a, off);
+        if (v1) r[1] = b.present ? lazy4_at(a, off + C) + lazy4_at(b, off + C) : lazy4_at(a, off + C);
+        if (v2) r[2] = b.present ? lazy4_at(a, off + 2 * C) + lazy4_at(b, off + 2 * C) : lazy4_at(a, off + 2 * C);
+      };
+      float4 t0[3], t1[3], t2[3];
+      load_row(r0 * S - 1, t0);
+      if (S == 1) load_row(r0, t1);
+      float* o = out + (((size_t)bi * d.Hd + r0) * d.Wd + ox) * C + c;
+      for (int oy = r0; oy < r1; ++oy, o += (size_t)d.Wd * C) {
+        if (S == 1) {
+          load_row(oy + 1, t2);
+        } else {
+          load_row(2 * oy, t1);
+          load_row(2 * oy + 1, t2);
+        }
+        float4 acc = t0[0] * wk[0];
+        acc = fma4(t0[1], wk[1], acc);
+        acc = fma4(t0[2], wk[2], acc);
+        acc = fma4(t1[0], wk[3], acc);
+        acc = fma4(t1[1], wk[4], acc);
+        acc = fma4(t1[2], wk[5], acc);
+        acc = fma4(t2[0], wk[6], acc);
+        acc = fma4(t2[1], wk[7], acc);
+        acc = fma4(t2[2], wk[8], acc);
+        st4(o, acc);
+        s1 = s1 + acc;
+        s2 = fma4(acc, acc, s2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (S == 1) {
+            t0[j] = t1[j];
+            t1[j] = t2[j];
+          } else {
+            t0[j] = t2[j];
+          }
+        }
+      }
+    }
+  }
+  if (slab != nullptr) {
+    const float4 v[2] = {s1, s2};
+    block_channel_reduce<2>(v, C, CG, PPB, red, slab + (size_t)blockIdx.x * 2 * C);
+  }
+}
+
+// forward, cell geometry (transposed convolution, stride 2)
+__global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                            float* __restrict__ out, float* __restrict__ slab,
+                                                            WalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (pl < PPB) {
+    const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+    float4 wk[9];
+    load_taps(w, c, false, wk);
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      int bi, m0, m1, mx;
+      if (!walk_slot(d, g * PPB + pl, d.Hs, bi, m0, m1, mx)) continue;
+      const bool vx1 = mx + 1 < d.Ws;         // source column mx+1 exists
+      const bool dx1 = 2 * mx + 1 < d.Wd;     // destination column 2mx+1 exists
+      const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
+      auto load_row = [&](int iy, float4& r0, float4& r1) {
+        r0 = r1 = f4(0.f);
+        if (iy >= d.Hs) return;
+        const size_t off = clip + ((size_t)iy * d.Ws + mx) * C;
+        r0 = b.present ? lazy4_at(a, off) + lazy4_at(b, off) : lazy4_at(a, off);
+        if (vx1) r1 = b.present ? lazy4_at(a, off + C) + lazy4_at(b, off + C) : lazy4_at(a, off + C);
+      };
+      float4 s00, s01, s10, s11;
+      load_row(m0, s00, s01);
+      float* o = out + (((size_t)bi * d.Hd + 2 * m0) * d.Wd + 2 * mx) * C + c;
+      const size_t drow = (size_t)d.Wd * C;
+      for (int m = m0; m < m1; ++m, o += 2 * drow) {
+        load_row(m + 1, s10, s11);
+        const float4 d00 = s00 * wk[4];
+        st4(o, d00);
+        s1 = s1 + d00;
+        s2 = fma4(d00, d00, s2);
+        if (dx1) {
+          const float4 d01 = fma4(s01, wk[3], s00 * wk[5]);
+          st4(o + C, d01);
+          s1 = s1 + d01;
+          s2 = fma4(d01, d01, s2);
+        }
+        if (2 * m + 1 < d.Hd) {
+          const float4 d10 = fma4(s10, wk[1], s00 * wk[7]);
+          st4(o + drow, d10);
+          s1 = s1 + d10;
+          s2 = fma4(d10, d10, s2);
+          if (dx1) {
+            float4 d11 = s00 * wk[8];
+            d11 = fma4(s01, wk[6], d11);
+            d11 = fma4(s10, wk[2], d11);
+            d11 = fma4(s11, wk[0], d11);
+            st4(o + drow + C, d11);
+            s1 = s1 + d11;
+            s2 = fma4(d11, d11, s2);
+          }
+        }
+        s00 = s10;
+        s01 = s11;
+      }
+    }
+  }
+  if (slab != nullptr) {
+    const float4 v[2] = {s1, s2};
+    block_channel_reduce<2>(v, C, CG, PPB, red, slab + (size_t)blockIdx.x * 2 * C);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: destination = the layer's input gradient g_in (and the activation a at the same pixels, for the
+// weight gradient), source = the lazy gradient dy of the layer's output.
+struct BwdPixel {
+  Lazy4 a, b;
+  Epi4 epi;
+  float* g_in;
+};
+
+// Finishes one destination pixel: weight-gradient contribution is done by the caller (it needs av), this applies
+// the epilogue and stores.
+__device__ __forceinline__ float4 bwd_activation(const BwdPixel& p, size_t off, float4& yraw) {
+  yraw = ld4(p.a.y + off);
+  float4 av = fma4(yraw, p.a.scale, p.a.shift);
+  if (p.a.act == ACT_RELU6) av = relu6_4(av);
+  if (p.b.present) av = av + lazy4_at(p.b, off);
+  return av;
+}
+
+template <int S, bool FLIP>
+__global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
+                                                              const float* __restrict__ w, float* __restrict__ g_in,
+                                                              float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 dwk[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) dwk[k] = f4(0.f);
+  if (pl < PPB) {
+    BwdPixel px{lazy4_init(A, C, c), lazy4_init(Bsrc, C, c), epi4_init(E, C, c), g_in};
+    const LazyGrad4 gr = lazygrad4_init(G, C, c);
+    float4 wk[9];
+    load_taps(w, c, FLIP, wk);
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      int bi, r0, r1, ox;
+      if (!walk_slot(d, g * PPB + pl, d.Hd, bi, r0, r1, ox)) continue;
+      const int ix0 = ox * S - 1;
+      const bool v0 = ix0 >= 0, v1 = ix0 + 1 < d.Ws, v2 = ix0 + 2 < d.Ws;
+      const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
+      auto load_row = [&](int iy, float4(&r)[3]) {
+        r[0] = r[1] = r[2] = f4(0.f);
+        if (iy < 0 || iy >= d.Hs) return;
+        const size_t off = clip + ((size_t)iy * d.Ws + ix0) * C;
+        if (v0) r[0] = lazygrad4_at(gr, off);
+        if (v1) r[1] = lazygrad4_at(gr, off + C);
+        if (v2) r[2] = lazygrad4_at(gr, off + 2 * C);
+      };
+      float4 t0[3], t1[3], t2[3];
+      load_row(r0 * S - 1, t0);
+      if (S == 1) load_row(r0, t1);
+      size_t ioff = (((size_t)bi * d.Hd + r0) * d.Wd + ox) * C + c;
+      for (int oy = r0; oy < r1; ++oy, ioff += (size_t)d.Wd * C) {
+        if (S == 1) {
+          load_row(oy + 1, t2);
+        } else {
+          load_row(2 * oy, t1);
+          load_row(2 * oy + 1, t2);
+        }
+        float4 yraw;
+        const float4 av = bwd_activation(px, ioff, yraw);
+        float4 acc = t0[0] * wk[0];
+        acc = fma4(t0[1], wk[1], acc);
+        acc = fma4(t0[2], wk[2], acc);
+        acc = fma4(t1[0], wk[3], acc);
+        acc = fma4(t1[1], wk[4], acc);
+        acc = fma4(t1[2], wk[5], acc);
+        acc = fma4(t2[0], wk[6], acc);
+        acc = fma4(t2[1], wk[7], acc);
+        acc = fma4(t2[2], wk[8], acc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dwk[j] = fma4(t0[j], av, dwk[j]);
+          dwk[3 + j] = fma4(t1[j], av, dwk[3 + j]);
+          dwk[6 + j] = fma4(t2[j], av, dwk[6 + j]);
+        }
+        acc = epi4_apply(px.epi, acc, yraw, ioff, dwk[9], dwk[10]);
+        if (g_in != nullptr) st4(g_in + ioff, acc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (S == 1) {
+            t0[j] = t1[j];
+            t1[j] = t2[j];
+          } else {
+            t0[j] = t2[j];
+          }
+        }
+      }
+    }
+    if (FLIP) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 t = dwk[k];
+        dwk[k] = dwk[8 - k];
+        dwk[8 - k] = t;
+      }
+    }
+  }
+  block_channel_reduce<11>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
+}
+
+// backward of a stride-2 Conv2d: cell geometry over dy
+__global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
+                                                            const float* __restrict__ w, float* __restrict__ g_in,
+                                                            float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 dwk[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) dwk[k] = f4(0.f);
+  if (pl < PPB) {
+    BwdPixel px{lazy4_init(A, C, c), lazy4_init(Bsrc, C, c), epi4_init(E, C, c), g_in};
+    const LazyGrad4 gr = lazygrad4_init(G, C, c);
+    float4 wk[9];
+    load_taps(w, c, false, wk);
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      int bi, m0, m1, mx;
+      if (!walk_slot(d, g * PPB + pl, d.Hs, bi, m0, m1, mx)) continue;
+      const bool vx1 = mx + 1 < d.Ws;
+      const bool dx1 = 2 * mx + 1 < d.Wd;
+      const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
+      auto load_row = [&](int iy, float4& r0, float4& r1) {
+        r0 = r1 = f4(0.f);
+        if (iy >= d.Hs) return;
+        const size_t off = clip + ((size_t)iy * d.Ws + mx) * C;
+        r0 = lazygrad4_at(gr, off);
+        if (vx1) r1 = lazygrad4_at(gr, off + C);
+      };
+      float4 s00, s01, s10, s11;
+      load_row(m0, s00, s01);
+      size_t ioff = (((size_t)bi * d.Hd + 2 * m0) * d.Wd + 2 * mx) * C + c;
+      const size_t drow = (size_t)d.Wd * C;
+      for (int m = m0; m < m1; ++m, ioff += 2 * drow) {
+        load_row(m + 1, s10, s11);
+        float4 yraw, av, gv;
+        av = bwd_activation(px, ioff, yraw);
+        gv = s00 * wk[4];
+        dwk[4] = fma4(s00, av, dwk[4]);
+        gv = epi4_apply(px.epi, gv, yraw, ioff, dwk[9], dwk[10]);
+        if (g_in != nullptr) st4(g_in + ioff, gv);
+        if (dx1) {
+          av = bwd_activation(px, ioff + C, yraw);
+          gv = fma4(s01, wk[3], s00 * wk[5]);
+          dwk[5] = fma4(s00, av, dwk[5]);
+          dwk[3] = fma4(s01, av, dwk[3]);
+          gv = epi4_apply(px.epi, gv, yraw, ioff + C, dwk[9], dwk[10]);
+          if (g_in != nullptr) st4(g_in + ioff + C, gv);
+        }
+        if (2 * m + 1 < d.Hd) {
+          av = bwd_activation(px, ioff + drow, yraw);
+          gv = fma4(s10, wk[1], s00 * wk[7]);
+          dwk[7] = fma4(s00, av, dwk[7]);
+          dwk[1] = fma4(s10, av, dwk[1]);
+          gv = epi4_apply(px.epi, gv, yraw, ioff + drow, dwk[9], dwk[10]);
+          if (g_in != nullptr) st4(g_in + ioff + drow, gv);
+          if (dx1) {
+            av = bwd_activation(px, ioff + drow + C, yraw);
+            gv = s00 * wk[8];
+            gv = fma4(s01, wk[6], gv);
+            gv = fma4(s10, wk[2], gv);
+            gv = fma4(s11, wk[0], gv);
+            dwk[8] = fma4(s00, av, dwk[8]);
+            dwk[6] = fma4(s01, av, dwk[6]);
+            dwk[2] = fma4(s10, av, dwk[2]);
+            dwk[0] = fma4(s11, av, dwk[0]);
+            gv = epi4_apply(px.epi, gv, yraw, ioff + drow + C, dwk[9], dwk[10]);
+            if (g_in != nullptr) st4(g_in + ioff + drow + C, gv);
+          }
+        }
+        s00 = s10;
+        s01 = s11;
+      }
+    }
+  }
+  block_channel_reduce<11>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
+}
+
+// Band layout: enough column slots to give every CU several workgroups, bands of at least 8 walked rows.
+inline void walk_plan(WalkDims& d, int walked_rows, int max_blocks, int& grid) {
+  const int PPB = 256 / (d.C / 4);
+  const long slots1 = (long)d.B * d.wown;
+  int nb = 1;
+  const long want = 2048L * PPB;
+  if (slots1 < want) {
+    nb = (int)((want + slots1 - 1) / slots1);
+    const int max_nb = walked_rows / 8 > 1 ? walked_rows / 8 : 1;
+    if (nb > max_nb) nb = max_nb;
+  }
+  d.bh = (walked_rows + nb - 1) / nb;
+  d.nb = (walked_rows + d.bh - 1) / d.bh;
+  d.ngroups = (int)(((long)d.B * d.nb * d.wown + PPB - 1) / PPB);
+  grid = d.ngroups < max_blocks ? d.ngroups : max_blocks;
+}
+
+}  // namespace

@@ -187,6 +187,65 @@ def build_model(models, n_fft, hop, max_frames=1200):
     return m
 
 
+def train_fixture(models, path, last_scale):
+    m = build_model(models, 320, 160)
+    if last_scale is not None:
+        with torch.no_grad():
+            m.model.decoder[-1][0].weight.mul_(last_scale)
+            m.model.decoder[-1][0].bias.zero_()
+        g3_extra = {"last_weight": _np(m.model.decoder[-1][0].weight), "last_bias": _np(m.model.decoder[-1][0].bias)}
+    else:
+        g3_extra = {}
+    # pre-run the padding search in eval mode so BatchNorm state stays clean
+    m.eval()
+    with torch.no_grad():
+        m(_wave(3, (1, 1, 1, 8000)))
+    m.train()
+    B = 4
+    clean = _wave(20, (B, 1, 1, 8000), std=0.05)
+    noise = _wave(21, (B, 1, 1, 8000), std=0.03)
+    clean[1] = 0.0                    # silent segment  -> VAD label 0
+    clean[2, ..., 100:] = 0.0         # 100 non-zero samples (<160) -> label 0
+    noisy = (clean + noise).clamp(-1, 1)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    # ScaledDotProductAttention is built with its default attn_dropout=0.1 (models.py:22,55),
+    # so train mode drops attention weights at random: record the keep-mask of each step.
+    masks = []
+    sdpa = m.model.bottleneck_attention.layer_stack[0].slf_attn.attention
+    sdpa.dropout.register_forward_hook(lambda mod, inp, out: masks.append((out != 0).numpy().copy()))
+    opt.zero_grad()
+    torch.manual_seed(1234)
+    loss = m.training_step((noisy, clean, ["a"] * B), 0)
+    loss.backward()
+    g3 = {"noisy": _np(noisy), "clean": _np(clean), "loss": _np(loss)}
+    g3.update(g3_extra)
+    for k, v in m._logged.items():
+        g3["log/" + k] = np.float32(v)
+    for k, p in m.named_parameters():
+        g3["grad/" + k] = _np(p.grad)
+    for k, b in m.named_buffers():
+        if "running" in k or "num_batches" in k:
+            g3["buf/" + k] = _np(b)
+    opt.step()
+    for k, p in m.named_parameters():
+        g3["param_after/" + k] = _np(p)
+    # second step (exercises Adam bias correction at t=2 and BN momentum)
+    opt.zero_grad()
+    torch.manual_seed(1235)
+    loss2 = m.training_step((noisy, clean, ["a"] * B), 1)
+    loss2.backward()
+    opt.step()
+    g3["loss2"] = _np(loss2)
+    assert len(masks) == 2
+    g3["attn_keep1"] = np.packbits(masks[0].reshape(-1))
+    g3["attn_keep2"] = np.packbits(masks[1].reshape(-1))
+    g3["attn_keep_shape"] = np.array(masks[0].shape, dtype=np.int64)
+    for k, p in m.named_parameters():
+        g3["param_after2/" + k] = _np(p)
+    np.savez(path, **g3)
+
+
+
 def main():
     _install_standins()
     sys.path.insert(0, os.path.join(REF, "train"))
@@ -245,53 +304,13 @@ def main():
         np.savez(os.path.join(OUT, f"g2_eval_forward_{tag}.npz"), **g2)
 
     # ------------------------------------------------------------------ G3: train step
-    m = build_model(models, 320, 160)
-    # pre-run the padding search in eval mode so BatchNorm state stays clean
-    m.eval()
-    with torch.no_grad():
-        m(_wave(3, (1, 1, 1, 8000)))
-    m.train()
-    B = 4
-    clean = _wave(20, (B, 1, 1, 8000), std=0.05)
-    noise = _wave(21, (B, 1, 1, 8000), std=0.03)
-    clean[1] = 0.0                    # silent segment  -> VAD label 0
-    clean[2, ..., 100:] = 0.0         # 100 non-zero samples (<160) -> label 0
-    noisy = (clean + noise).clamp(-1, 1)
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
-    # ScaledDotProductAttention is built with its default attn_dropout=0.1 (models.py:22,55),
-    # so train mode drops attention weights at random: record the keep-mask of each step.
-    masks = []
-    sdpa = m.model.bottleneck_attention.layer_stack[0].slf_attn.attention
-    sdpa.dropout.register_forward_hook(lambda mod, inp, out: masks.append((out != 0).numpy().copy()))
-    opt.zero_grad()
-    torch.manual_seed(1234)
-    loss = m.training_step((noisy, clean, ["a"] * B), 0)
-    loss.backward()
-    g3 = {"noisy": _np(noisy), "clean": _np(clean), "loss": _np(loss)}
-    for k, v in m._logged.items():
-        g3["log/" + k] = np.float32(v)
-    for k, p in m.named_parameters():
-        g3["grad/" + k] = _np(p.grad)
-    for k, b in m.named_buffers():
-        if "running" in k or "num_batches" in k:
-            g3["buf/" + k] = _np(b)
-    opt.step()
-    for k, p in m.named_parameters():
-        g3["param_after/" + k] = _np(p)
-    # second step (exercises Adam bias correction at t=2 and BN momentum)
-    opt.zero_grad()
-    torch.manual_seed(1235)
-    loss2 = m.training_step((noisy, clean, ["a"] * B), 1)
-    loss2.backward()
-    opt.step()
-    g3["loss2"] = _np(loss2)
-    assert len(masks) == 2
-    g3["attn_keep1"] = np.packbits(masks[0].reshape(-1))
-    g3["attn_keep2"] = np.packbits(masks[1].reshape(-1))
-    g3["attn_keep_shape"] = np.array(masks[0].shape, dtype=np.int64)
-    for k, p in m.named_parameters():
-        g3["param_after2/" + k] = _np(p)
-    np.savez(os.path.join(OUT, "g3_train_step.npz"), **g3)
+    # Two fixtures.  "g3_train_step" uses the perturbed random weights as they are: about half of the enhanced
+    # log-magnitudes then sit on the [-1, 1] clamp of models.py:763, and an element within a few ulps of the clamp
+    # changes individual gradients by several per cent when it tips over, so it pins losses, statistics and the
+    # bulk of the gradients.  "g3t_train_step" shrinks the last layer (weight * 0.05, zero bias) so that the clamp
+    # is rarely active and a tight fp32 tolerance on every gradient and updated parameter is meaningful.
+    for fname, last_scale in (("g3_train_step.npz", None), ("g3t_train_step.npz", 0.05)):
+        train_fixture(models, os.path.join(OUT, fname), last_scale)
 
     # ------------------------------------------------------------------ G4: mixer
     g4 = {}

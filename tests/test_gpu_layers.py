@@ -74,6 +74,10 @@ def slab_stats(slab, rows, C):
     (96, (2, 2), True, False, (2, 6, 4)),
     (72, (2, 2), True, False, (1, 41, 17)),
     (16, (1, 1), True, True, (2, 9, 6)),
+    (16, (1, 1), True, True, (4, 81, 33)),
+    (32, (1, 1), False, False, (4, 81, 33)),
+    (72, (2, 2), True, False, (4, 41, 17)),
+    (192, (2, 2), True, False, (4, 11, 5)),
 ])
 def test_depthwise(dev, C, stride, transposed, two_src, shape):
     from noise_amd import ops
@@ -234,7 +238,7 @@ def test_first_conv(dev, B, H, W, hp, wp):
     close(dw, w.grad, 1e-4, "wgrad")
 
 
-@pytest.mark.parametrize("B,Hi,Wi,H,W", [(2, 81, 33, 161, 51), (1, 9, 6, 17, 11), (2, 5, 5, 9, 9)])
+@pytest.mark.parametrize("B,Hi,Wi,H,W", [(2, 81, 33, 161, 51), (4, 81, 33, 161, 51), (1, 9, 6, 17, 11), (2, 5, 5, 9, 9)])
 def test_last_convT(dev, B, Hi, Wi, H, W):
     from noise_amd import ops
     g = torch.Generator().manual_seed(Hi)

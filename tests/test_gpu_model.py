@@ -61,22 +61,45 @@ def _keep(g, which, dev):
     return torch.from_numpy(bits.astype(np.uint8)).to(dev).contiguous()
 
 
-def _check_grads(named_grads, g, tol=2e-3):
-    worst = ("", 0.0)
+FIXTURES = ["g3t_train_step.npz", "g3_train_step.npz"]
+
+
+def _load_train_fixture(golden_dir, fixture, dev, n_fft=320, hop=160):
+    g = np.load(os.path.join(golden_dir, fixture))
+    m = build(n_fft, hop, dev, golden_dir)
+    tame = "last_weight" in g.files
+    if tame:
+        with torch.no_grad():
+            m.model.decoder[-1][0].weight.copy_(torch.from_numpy(g["last_weight"]))
+            m.model.decoder[-1][0].bias.copy_(torch.from_numpy(g["last_bias"]))
+    return g, m.train(), tame
+
+
+def _check_grads(named_grads, g, tame, tol=2e-3):
+    """`tame` fixture (shrunken last layer, clamp of models.py:763 rarely active): every gradient within `tol`
+    of the reference's, relative to the largest entry of that parameter.  Untamed fixture: half of the enhanced
+    log-magnitudes sit on the clamp and the one element within 2e-6 of it (clip 3, bin 73, frame 36, which also
+    carries a large waveform-loss gradient) tips over with the summation order of the BatchNorm statistics,
+    moving every gradient by a few per cent (up to ~17 %); there no parameter may be off by more than 30 %,
+    and the tight comparison is the `tame` fixture's."""
+    errs = {}
     for k, gr in named_grads:
         ref = g["grad/" + k]
         # analytically-zero gradients (biases feeding a train-mode BatchNorm) are rounding noise on both sides
         scale = max(np.abs(ref).max(), 1e-4)
-        e = np.abs(gr.detach().cpu().numpy() - ref).max() / scale
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < tol, f"gradient mismatch {worst}"
+        errs[k] = float(np.abs(gr.detach().cpu().numpy() - ref).max() / scale)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    if tame:
+        assert worst[1] < tol, f"gradient mismatch {worst}"
+    else:
+        assert worst[1] < 0.3, f"gradient mismatch {worst}"
+    return worst[1] < tol
 
 
-def test_train_step_golden_fused(dev, golden_dir):
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_train_step_golden_fused(dev, golden_dir, fixture):
     """Fused path: forward + loss + backward + AdamW without autograd, two consecutive steps."""
-    g = np.load(os.path.join(golden_dir, "g3_train_step.npz"))
-    m = build(320, 160, dev, golden_dir).train()
+    g, m, tame = _load_train_fixture(golden_dir, fixture, dev)
     opt = m.configure_optimizers()
     noisy, clean = torch.from_numpy(g["noisy"]).to(dev), torch.from_numpy(g["clean"]).to(dev)
     m.attn_keep_mask = _keep(g, "attn_keep1", dev)
@@ -84,7 +107,7 @@ def test_train_step_golden_fused(dev, golden_dir):
     # per-step loss in fp32: 1e-4 relative
     for i, k in enumerate(("loss", "vad_loss", "waveform_loss", "spectral_loss")):
         np.testing.assert_allclose(out4[i], g[f"log/train_{k}"], rtol=1e-4, err_msg=k)
-    _check_grads([(k, p.grad) for k, p in m.named_parameters()], g)
+    grads_tight = _check_grads([(k, p.grad) for k, p in m.named_parameters()], g, tame)
     for k, b in m.named_buffers():
         if "running" in k:
             np.testing.assert_allclose(b.cpu().numpy(), g["buf/" + k], rtol=1e-4, atol=1e-6, err_msg=k)
@@ -94,17 +117,18 @@ def test_train_step_golden_fused(dev, golden_dir):
         solid = np.abs(g["grad/" + k]) > 1e-5
         ref = g["param_after/" + k]
         got = p.detach().cpu().numpy()
-        np.testing.assert_allclose(got[solid], ref[solid], atol=5e-6, err_msg=k)
+        if grads_tight:     # Adam's first update is lr*sign(g): only meaningful where the gradients agree
+            np.testing.assert_allclose(got[solid], ref[solid], atol=5e-6, err_msg=k)
         assert np.abs(got - ref).max() <= 2.1e-4, k
     m.attn_keep_mask = _keep(g, "attn_keep2", dev)
     out4 = m.train_step_fused(noisy, clean, opt).cpu().numpy()
     np.testing.assert_allclose(out4[0], g["loss2"], rtol=2e-4)
 
 
-def test_train_step_golden_autograd(dev, golden_dir):
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_train_step_golden_autograd(dev, golden_dir, fixture):
     """Drop-in path: training_step(...) returns a loss whose .backward() fills p.grad; torch.optim.AdamW steps."""
-    g = np.load(os.path.join(golden_dir, "g3_train_step.npz"))
-    m = build(320, 160, dev, golden_dir).train()
+    g, m, tame = _load_train_fixture(golden_dir, fixture, dev)
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
     noisy, clean = torch.from_numpy(g["noisy"]).to(dev), torch.from_numpy(g["clean"]).to(dev)
     m.attn_keep_mask = _keep(g, "attn_keep1", dev)
@@ -114,11 +138,12 @@ def test_train_step_golden_autograd(dev, golden_dir):
     loss.backward()
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
     assert set(m.logged_metrics) == {"train_loss", "train_vad_loss", "train_waveform_loss", "train_spectral_loss"}
-    _check_grads([(k, p.grad) for k, p in m.named_parameters()], g)
+    grads_tight = _check_grads([(k, p.grad) for k, p in m.named_parameters()], g, tame)
     opt.step()
     for k, p in m.named_parameters():
         solid = np.abs(g["grad/" + k]) > 1e-5
-        np.testing.assert_allclose(p.detach().cpu().numpy()[solid], g["param_after/" + k][solid], atol=5e-6, err_msg=k)
+        if grads_tight:
+            np.testing.assert_allclose(p.detach().cpu().numpy()[solid], g["param_after/" + k][solid], atol=5e-6, err_msg=k)
     # validation: eval-mode BatchNorm, no dropout, no gradient
     m.eval()
     with torch.no_grad():
