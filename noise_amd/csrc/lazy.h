@@ -115,8 +115,13 @@ __device__ __forceinline__ Epi4 epi4_init(const BwdEpilogue& e, int C, int c) {
 
 // Applies the epilogue to gradient g of the element whose raw producer output is yraw; accumulates the
 // two BatchNorm-backward sums.  Returns the value to store.
-__device__ __forceinline__ float4 epi4_apply(const Epi4& e, float4 g, float4 yraw, size_t off, float4& s1, float4& s2) {
-  if (e.g_other) g = g + ld4(e.g_other + off);
+// `ok` = false marks a pixel that does not exist (its g must already be zero): nothing is accumulated for it.
+__device__ __forceinline__ float4 epi4_apply(const Epi4& e, float4 g, float4 yraw, size_t off, float4& s1, float4& s2,
+                                             bool ok = true) {
+  if (e.g_other) {
+    const float4 o = ld4(e.g_other + off);
+    g = g + make_float4(ok ? o.x : 0.f, ok ? o.y : 0.f, ok ? o.z : 0.f, ok ? o.w : 0.f);
+  }
   if (e.stats) {
     if (e.relu6) {
       const float4 v = fma4(yraw, e.scale, e.shift);

@@ -38,6 +38,10 @@ __device__ __forceinline__ void load_taps(const float* __restrict__ w, int c, bo
   }
 }
 
+__device__ __forceinline__ float4 keep4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 // Decode a column slot: clip, band rows [r0, r1) and owned column.
 __device__ __forceinline__ bool walk_slot(const WalkDims& d, int slot, int nrows, int& bi, int& r0, int& r1, int& col) {
   if (slot >= d.B * d.nb * d.wown) return false;
@@ -70,13 +74,22 @@ __global__ __launch_bounds__(256) void walk_gather_fwd_kernel(LazySrc A, LazySrc
       const int ix0 = ox * S - 1;
       const bool v0 = ix0 >= 0, v1 = ix0 + 1 < d.Ws, v2 = ix0 + 2 < d.Ws;
       const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
+      // branch-free: a tap outside the source reads a clamped (valid) address and is zeroed afterwards, so all
+      // loads of a step are issued back to back
+      const int cx0 = v0 ? ix0 : 0, cx1 = v1 ? ix0 + 1 : 0, cx2 = v2 ? ix0 + 2 : 0;
       auto load_row = [&](int iy, float4(&r)[3]) {
-        r[0] = r[1] = r[2] = f4(0.f);
-        if (iy < 0 || iy >= d.Hs) return;
-        const size_t off = clip + ((size_t)iy * d.Ws + ix0) * C;   // ix0 = -1 is never dereferenced
-        if (v0) r[0] = b.present ? lazy4_at(a, off) + lazy4_at(b, off) : lazy4_at(a, off);
-        if (v1) r[1] = b.present ? lazy4_at(a, off + C) + lazy4_at(b, off + C) : lazy4_at(a, off + C);
-        if (v2) r[2] = b.present ? lazy4_at(a, off + 2 * C) + lazy4_at(b, off + 2 * C) : lazy4_at(a, off + 2 * C);
+        const bool vy = iy >= 0 && iy < d.Hs;
+        const size_t row = clip + (size_t)(vy ? iy : 0) * d.Ws * C;
+        const size_t o0 = row + (size_t)cx0 * C, o1 = row + (size_t)cx1 * C, o2 = row + (size_t)cx2 * C;
+        float4 x0 = lazy4_at(a, o0), x1 = lazy4_at(a, o1), x2 = lazy4_at(a, o2);
+        if (b.present) {
+          x0 = x0 + lazy4_at(b, o0);
+          x1 = x1 + lazy4_at(b, o1);
+          x2 = x2 + lazy4_at(b, o2);
+        }
+        r[0] = keep4(vy && v0, x0);
+        r[1] = keep4(vy && v1, x1);
+        r[2] = keep4(vy && v2, x2);
       };
       float4 t0[3], t1[3], t2[3];
       load_row(r0 * S - 1, t0);
@@ -137,12 +150,16 @@ __global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc B
       const bool vx1 = mx + 1 < d.Ws;         // source column mx+1 exists
       const bool dx1 = 2 * mx + 1 < d.Wd;     // destination column 2mx+1 exists
       const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
-      auto load_row = [&](int iy, float4& r0, float4& r1) {
-        r0 = r1 = f4(0.f);
-        if (iy >= d.Hs) return;
-        const size_t off = clip + ((size_t)iy * d.Ws + mx) * C;
-        r0 = b.present ? lazy4_at(a, off) + lazy4_at(b, off) : lazy4_at(a, off);
-        if (vx1) r1 = b.present ? lazy4_at(a, off + C) + lazy4_at(b, off + C) : lazy4_at(a, off + C);
+      auto load_row = [&](int iy, float4& r0, float4& r1) {   // branch-free, see walk_gather_fwd_kernel
+        const bool vy = iy < d.Hs;
+        const size_t o0 = clip + ((size_t)(vy ? iy : 0) * d.Ws + mx) * C, o1 = vx1 ? o0 + C : o0;
+        float4 x0 = lazy4_at(a, o0), x1 = lazy4_at(a, o1);
+        if (b.present) {
+          x0 = x0 + lazy4_at(b, o0);
+          x1 = x1 + lazy4_at(b, o1);
+        }
+        r0 = keep4(vy, x0);
+        r1 = keep4(vy && vx1, x1);
       };
       float4 s00, s01, s10, s11;
       load_row(m0, s00, s01);
@@ -226,18 +243,22 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
       const int ix0 = ox * S - 1;
       const bool v0 = ix0 >= 0, v1 = ix0 + 1 < d.Ws, v2 = ix0 + 2 < d.Ws;
       const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
-      auto load_row = [&](int iy, float4(&r)[3]) {
-        r[0] = r[1] = r[2] = f4(0.f);
-        if (iy < 0 || iy >= d.Hs) return;
-        const size_t off = clip + ((size_t)iy * d.Ws + ix0) * C;
-        if (v0) r[0] = lazygrad4_at(gr, off);
-        if (v1) r[1] = lazygrad4_at(gr, off + C);
-        if (v2) r[2] = lazygrad4_at(gr, off + 2 * C);
+      const int cx0 = v0 ? ix0 : 0, cx1 = v1 ? ix0 + 1 : 0, cx2 = v2 ? ix0 + 2 : 0;
+      auto load_row = [&](int iy, float4(&r)[3]) {   // branch-free, see walk_gather_fwd_kernel
+        const bool vy = iy >= 0 && iy < d.Hs;
+        const size_t row = clip + (size_t)(vy ? iy : 0) * d.Ws * C;
+        const float4 x0 = lazygrad4_at(gr, row + (size_t)cx0 * C);
+        const float4 x1 = lazygrad4_at(gr, row + (size_t)cx1 * C);
+        const float4 x2 = lazygrad4_at(gr, row + (size_t)cx2 * C);
+        r[0] = keep4(vy && v0, x0);
+        r[1] = keep4(vy && v1, x1);
+        r[2] = keep4(vy && v2, x2);
       };
       float4 t0[3], t1[3], t2[3];
       load_row(r0 * S - 1, t0);
       if (S == 1) load_row(r0, t1);
       size_t ioff = (((size_t)bi * d.Hd + r0) * d.Wd + ox) * C + c;
+#pragma unroll 1
       for (int oy = r0; oy < r1; ++oy, ioff += (size_t)d.Wd * C) {
         if (S == 1) {
           load_row(oy + 1, t2);
@@ -308,53 +329,53 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
       const bool vx1 = mx + 1 < d.Ws;
       const bool dx1 = 2 * mx + 1 < d.Wd;
       const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
-      auto load_row = [&](int iy, float4& r0, float4& r1) {
-        r0 = r1 = f4(0.f);
-        if (iy >= d.Hs) return;
-        const size_t off = clip + ((size_t)iy * d.Ws + mx) * C;
-        r0 = lazygrad4_at(gr, off);
-        if (vx1) r1 = lazygrad4_at(gr, off + C);
+      auto load_row = [&](int iy, float4& r0, float4& r1) {   // branch-free, see walk_gather_fwd_kernel
+        const bool vy = iy < d.Hs;
+        const size_t o0 = clip + ((size_t)(vy ? iy : 0) * d.Ws + mx) * C;
+        const float4 x0 = lazygrad4_at(gr, o0), x1 = lazygrad4_at(gr, vx1 ? o0 + C : o0);
+        r0 = keep4(vy, x0);
+        r1 = keep4(vy && vx1, x1);
       };
       float4 s00, s01, s10, s11;
       load_row(m0, s00, s01);
       size_t ioff = (((size_t)bi * d.Hd + 2 * m0) * d.Wd + 2 * mx) * C + c;
       const size_t drow = (size_t)d.Wd * C;
+#pragma unroll 1
       for (int m = m0; m < m1; ++m, ioff += 2 * drow) {
         load_row(m + 1, s10, s11);
-        float4 yraw, av, gv;
-        av = bwd_activation(px, ioff, yraw);
-        gv = s00 * wk[4];
-        dwk[4] = fma4(s00, av, dwk[4]);
-        gv = epi4_apply(px.epi, gv, yraw, ioff, dwk[9], dwk[10]);
-        if (g_in != nullptr) st4(g_in + ioff, gv);
-        if (dx1) {
-          av = bwd_activation(px, ioff + C, yraw);
-          gv = fma4(s01, wk[3], s00 * wk[5]);
-          dwk[5] = fma4(s00, av, dwk[5]);
-          dwk[3] = fma4(s01, av, dwk[3]);
-          gv = epi4_apply(px.epi, gv, yraw, ioff + C, dwk[9], dwk[10]);
-          if (g_in != nullptr) st4(g_in + ioff + C, gv);
-        }
-        if (2 * m + 1 < d.Hd) {
-          av = bwd_activation(px, ioff + drow, yraw);
-          gv = fma4(s10, wk[1], s00 * wk[7]);
-          dwk[7] = fma4(s00, av, dwk[7]);
-          dwk[1] = fma4(s10, av, dwk[1]);
-          gv = epi4_apply(px.epi, gv, yraw, ioff + drow, dwk[9], dwk[10]);
-          if (g_in != nullptr) st4(g_in + ioff + drow, gv);
-          if (dx1) {
-            av = bwd_activation(px, ioff + drow + C, yraw);
-            gv = s00 * wk[8];
-            gv = fma4(s01, wk[6], gv);
-            gv = fma4(s10, wk[2], gv);
-            gv = fma4(s11, wk[0], gv);
-            dwk[8] = fma4(s00, av, dwk[8]);
-            dwk[6] = fma4(s01, av, dwk[6]);
-            dwk[2] = fma4(s10, av, dwk[2]);
-            dwk[0] = fma4(s11, av, dwk[0]);
-            gv = epi4_apply(px.epi, gv, yraw, ioff + drow + C, dwk[9], dwk[10]);
-            if (g_in != nullptr) st4(g_in + ioff + drow + C, gv);
-          }
+        // the four destination pixels of this cell; a pixel outside the tensor is redirected to (2m, 2mx), its
+        // loads are harmless and its results are neither accumulated nor stored
+        const bool ok01 = dx1, ok10 = 2 * m + 1 < d.Hd, ok11 = ok10 && dx1;
+        const size_t o00 = ioff, o01 = ok01 ? ioff + C : ioff, o10 = ok10 ? ioff + drow : ioff,
+                     o11 = ok11 ? ioff + drow + C : ioff;
+        float4 y00, y01, y10, y11;
+        const float4 a00 = bwd_activation(px, o00, y00), a01 = keep4(ok01, bwd_activation(px, o01, y01));
+        const float4 a10 = keep4(ok10, bwd_activation(px, o10, y10)), a11 = keep4(ok11, bwd_activation(px, o11, y11));
+        float4 g00 = s00 * wk[4];
+        float4 g01 = fma4(s01, wk[3], s00 * wk[5]);
+        float4 g10 = fma4(s10, wk[1], s00 * wk[7]);
+        float4 g11 = s00 * wk[8];
+        g11 = fma4(s01, wk[6], g11);
+        g11 = fma4(s10, wk[2], g11);
+        g11 = fma4(s11, wk[0], g11);
+        dwk[4] = fma4(s00, a00, dwk[4]);
+        dwk[5] = fma4(s00, a01, dwk[5]);
+        dwk[3] = fma4(s01, a01, dwk[3]);
+        dwk[7] = fma4(s00, a10, dwk[7]);
+        dwk[1] = fma4(s10, a10, dwk[1]);
+        dwk[8] = fma4(s00, a11, dwk[8]);
+        dwk[6] = fma4(s01, a11, dwk[6]);
+        dwk[2] = fma4(s10, a11, dwk[2]);
+        dwk[0] = fma4(s11, a11, dwk[0]);
+        g00 = epi4_apply(px.epi, g00, y00, o00, dwk[9], dwk[10]);
+        g01 = epi4_apply(px.epi, keep4(ok01, g01), y01, o01, dwk[9], dwk[10], ok01);
+        g10 = epi4_apply(px.epi, keep4(ok10, g10), y10, o10, dwk[9], dwk[10], ok10);
+        g11 = epi4_apply(px.epi, keep4(ok11, g11), y11, o11, dwk[9], dwk[10], ok11);
+        if (g_in != nullptr) {
+          st4(g_in + o00, g00);
+          if (ok01) st4(g_in + o01, g01);
+          if (ok10) st4(g_in + o10, g10);
+          if (ok11) st4(g_in + o11, g11);
         }
         s00 = s10;
         s01 = s11;
