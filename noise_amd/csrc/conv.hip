@@ -623,7 +623,13 @@ NOISE_EXPORT int noise_last_convT_fwd(const float* a_y, const float* a_coef, int
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   if (check_size("noise_last_convT_fwd", (long)B * Hfull * Wfull, C)) return -1;
   const int CG = C / 4;
-  if (CG <= 16 && (CG & (CG - 1)) == 0) {
+  if (sy == 2 && sx == 2 && CG >= 4 && CG <= 16 && (CG & (CG - 1)) == 0) {
+    LastWalkDims wd{B, Hi, Wi, C, H, W, Hfull - H, Wfull - W, 0, 0, 0, 0, 0, 0};
+    int grid;
+    last_walk_plan(wd, true, 4096, grid);
+    hipLaunchKernelGGL(last_cell_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag, absmax,
+                       enh, filt, wd);
+  } else if (CG <= 16 && (CG & (CG - 1)) == 0) {
     const int grid = noise_grid((long)B * H * W, 256 / CG, 8192);
     hipLaunchKernelGGL(last_convT_fwd_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
                        absmax, enh, filt, d);
@@ -649,13 +655,20 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
   NOISE_REQUIRE(Hfull >= H && Wfull >= W, "noise_last_convT_bwd: bad crop");
   LastDims d{B, Hi, Wi, C, sy, sx, H, W, Hfull - H, Wfull - W};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
-  const int grid = conv_grid((long)B * Hi * Wi, C);
+  int grid = conv_grid((long)B * Hi * Wi, C);
   const int PPB = 256 / (C / 4);
   hipStream_t st = (hipStream_t)stream;
   BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
+  if (sy == 2 && sx == 2) {
+    LastWalkDims wd{B, Hi, Wi, C, H, W, Hfull - H, Wfull - W, 0, 0, 0, 0, 0, 0};
+    last_walk_plan(wd, false, noise_conv_max_blocks(), grid);
+    hipLaunchKernelGGL(last_gather_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
+                       absmax, A, Bs, w, g_in, scratch, E, wd);
+  } else {
+    hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
+                       absmax, A, Bs, w, g_in, scratch, E, d);
+  }
   if (slab_rows) *slab_rows = grid;
-  hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
-                     absmax, A, Bs, w, g_in, scratch, E, d);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 12 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd/reduce");

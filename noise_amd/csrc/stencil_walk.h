@@ -402,4 +402,183 @@ inline void walk_plan(WalkDims& d, int walked_rows, int max_blocks, int& grid) {
   grid = d.ngroups < max_blocks ? d.ngroups : max_blocks;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Last layer (train/models.py:1164-1171 with the crop of :610 and the mask of :762-763), stride 2, C/4 a power
+// of two in [4,16]: the same two geometries with the channel sum spread over the C/4 lanes of a column.
+struct LastWalkDims {
+  int B, Hi, Wi, C;     // input (B, Hi, Wi, C)
+  int H, W, oy0, ox0;   // output crop: H x W starting at (oy0, ox0) of the full (2Hi-1) x (2Wi-1) output
+  int m_lo, x_lo;       // first walked input row / owned input column (earlier ones only feed cropped outputs)
+  int wown, nb, bh, ngroups;
+};
+
+// forward: filt(Y, X) = bias + sum_c sum_k a[(Y+1-ky)/2][(X+1-kx)/2][c] * w[c][k];  enh = clamp(x/max + filt)*max
+__global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ logmag,
+                                                            const float* __restrict__ absmax, float* __restrict__ enh,
+                                                            float* __restrict__ filt_out, LastWalkDims d) {
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+  float4 wk[9];
+  load_taps(w, c, false, wk);
+  const float bv = bias[0];
+  const int nslots = d.B * d.nb * d.wown;
+  const int p = (cg >> 1) & 1, q = cg & 1;   // lanes 0..3 of a column finish outputs (p, q) of its 2x2 cell
+  for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {   // uniform trip counts: the lane shuffles need whole waves
+    const int slot = g * PPB + pl;
+    const bool valid = slot < nslots;
+    const int sl = valid ? slot : 0;
+    const int mx = d.x_lo + sl % d.wown;
+    const int u = sl / d.wown;
+    const int band = u % d.nb, bi = u / d.nb;
+    const int m0 = d.m_lo + band * d.bh;
+    const int m1 = valid ? (m0 + d.bh < d.Hi ? m0 + d.bh : d.Hi) : m0;
+    const bool vx1 = mx + 1 < d.Wi;
+    const size_t clip = (size_t)bi * d.Hi * d.Wi * C + c;
+    auto load_row = [&](int iy, float4& r0, float4& r1) {   // branch-free: clamped address, zeroed afterwards
+      const bool vy = iy < d.Hi;
+      const size_t o0 = clip + ((size_t)(vy ? iy : 0) * d.Wi + mx) * C, o1 = vx1 ? o0 + C : o0;
+      float4 x0 = lazy4_at(a, o0), x1 = lazy4_at(a, o1);
+      if (b.present) {
+        x0 = x0 + lazy4_at(b, o0);
+        x1 = x1 + lazy4_at(b, o1);
+      }
+      r0 = keep4(vy, x0);
+      r1 = keep4(vy && vx1, x1);
+    };
+    const float mxv = absmax ? absmax[bi] + 1e-6f : 1.f;
+    float4 s00, s01, s10, s11;
+    load_row(m0, s00, s01);
+    const int X = 2 * mx + q - d.ox0;
+    for (int m = m0; m < m0 + d.bh; ++m) {
+      load_row(m + 1, s10, s11);
+      float4 t00 = s00 * wk[4];
+      float4 t01 = fma4(s01, wk[3], s00 * wk[5]);
+      float4 t10 = fma4(s10, wk[1], s00 * wk[7]);
+      float4 t11 = s00 * wk[8];
+      t11 = fma4(s01, wk[6], t11);
+      t11 = fma4(s10, wk[2], t11);
+      t11 = fma4(s11, wk[0], t11);
+      float p00 = (t00.x + t00.y) + (t00.z + t00.w), p01 = (t01.x + t01.y) + (t01.z + t01.w);
+      float p10 = (t10.x + t10.y) + (t10.z + t10.w), p11 = (t11.x + t11.y) + (t11.z + t11.w);
+      for (int o = CG >> 1; o > 0; o >>= 1) {
+        p00 += __shfl_xor(p00, o, 64);
+        p01 += __shfl_xor(p01, o, 64);
+        p10 += __shfl_xor(p10, o, 64);
+        p11 += __shfl_xor(p11, o, 64);
+      }
+      const float f = (p ? (q ? p11 : p10) : (q ? p01 : p00)) + bv;
+      const int Y = 2 * m + p - d.oy0;
+      if (cg < 4 && m < m1 && Y >= 0 && Y < d.H && X >= 0 && X < d.W) {
+        const size_t o = ((size_t)bi * d.H + Y) * d.W + X;
+        if (filt_out) filt_out[o] = f;
+        if (enh) {
+          const float v = logmag[o] / mxv + f;
+          enh[o] = fminf(fmaxf(v, -1.f), 1.f) * mxv;
+        }
+      }
+      s00 = s10;
+      s01 = s11;
+    }
+  }
+}
+
+// backward: dy0(Y, X) = d_enh * max * [|enh| < max] inside the crop, 0 outside;
+//   g_in[i][c] = sum_k dy0(2i - 1 + k) * w[c][k];   dW[c][k] += a[i][c] * dy0(2i - 1 + k);   db = sum dy0
+// Slab rows are 12*C floats: 9 taps | bias gradient at column 9*C | producer BatchNorm sums at [10C, 12C).
+__global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __restrict__ d_enh, const float* __restrict__ enh,
+                                                              const float* __restrict__ absmax, LazySrc A, LazySrc Bsrc,
+                                                              const float* __restrict__ w, float* __restrict__ g_in,
+                                                              float* __restrict__ dw_slab, BwdEpilogue E, LastWalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 dwk[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) dwk[k] = f4(0.f);
+  if (pl < PPB) {
+    const BwdPixel px{lazy4_init(A, C, c), lazy4_init(Bsrc, C, c), epi4_init(E, C, c), g_in};
+    float4 wk[9];
+    load_taps(w, c, false, wk);
+    float db = 0.f;
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      const int slot = g * PPB + pl;
+      if (slot >= d.B * d.nb * d.wown) continue;
+      const int ix = slot % d.wown;
+      const int u = slot / d.wown;
+      const int band = u % d.nb, bi = u / d.nb;
+      const int r0 = band * d.bh, r1 = r0 + d.bh < d.Hi ? r0 + d.bh : d.Hi;
+      const float mxv = absmax[bi] + 1e-6f;
+      const int X0 = 2 * ix - 1 - d.ox0;   // cropped column of tap kx = 0
+      const bool v0 = X0 >= 0 && X0 < d.W, v1 = X0 + 1 >= 0 && X0 + 1 < d.W, v2 = X0 + 2 >= 0 && X0 + 2 < d.W;
+      const int c0 = v0 ? X0 : 0, c1 = v1 ? X0 + 1 : 0, c2 = v2 ? X0 + 2 : 0;
+      const size_t oclip = (size_t)bi * d.H * d.W;
+      auto load_row = [&](int Y, float (&r)[3]) {   // Y: cropped output row; branch-free
+        const bool vy = Y >= 0 && Y < d.H;
+        const size_t row = oclip + (size_t)(vy ? Y : 0) * d.W;
+        const float e0 = enh[row + c0], e1 = enh[row + c1], e2 = enh[row + c2];
+        const float g0 = d_enh[row + c0], g1 = d_enh[row + c1], g2 = d_enh[row + c2];
+        r[0] = (vy && v0 && e0 > -mxv && e0 < mxv) ? g0 * mxv : 0.f;
+        r[1] = (vy && v1 && e1 > -mxv && e1 < mxv) ? g1 * mxv : 0.f;
+        r[2] = (vy && v2 && e2 > -mxv && e2 < mxv) ? g2 * mxv : 0.f;
+      };
+      float t0[3], t1[3], t2[3];
+      load_row(2 * r0 - 1 - d.oy0, t0);
+      size_t ioff = (((size_t)bi * d.Hi + r0) * d.Wi + ix) * C + c;
+      for (int iy = r0; iy < r1; ++iy, ioff += (size_t)d.Wi * C) {
+        load_row(2 * iy - d.oy0, t1);
+        load_row(2 * iy + 1 - d.oy0, t2);
+        float4 yraw;
+        const float4 av = bwd_activation(px, ioff, yraw);
+        float4 acc = f4(t0[0]) * wk[0];
+        acc = fma4(f4(t0[1]), wk[1], acc);
+        acc = fma4(f4(t0[2]), wk[2], acc);
+        acc = fma4(f4(t1[0]), wk[3], acc);
+        acc = fma4(f4(t1[1]), wk[4], acc);
+        acc = fma4(f4(t1[2]), wk[5], acc);
+        acc = fma4(f4(t2[0]), wk[6], acc);
+        acc = fma4(f4(t2[1]), wk[7], acc);
+        acc = fma4(f4(t2[2]), wk[8], acc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dwk[j] = fma4(f4(t0[j]), av, dwk[j]);
+          dwk[3 + j] = fma4(f4(t1[j]), av, dwk[3 + j]);
+          dwk[6 + j] = fma4(f4(t2[j]), av, dwk[6 + j]);
+        }
+        // every output (Y, X) is tap (1|2, 1|2) of exactly one input pixel: those four carry the bias gradient
+        db += (t1[1] + t1[2]) + (t2[1] + t2[2]);
+        acc = epi4_apply(px.epi, acc, yraw, ioff, dwk[10], dwk[11]);
+        st4(g_in + ioff, acc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t0[j] = t2[j];
+      }
+    }
+    if (cg == 0) dwk[9].x = db;
+  }
+  block_channel_reduce<12>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 12 * C);
+}
+
+inline void last_walk_plan(LastWalkDims& d, bool fwd, int max_blocks, int& grid) {
+  const int PPB = 256 / (d.C / 4);
+  d.m_lo = fwd ? d.oy0 / 2 : 0;
+  d.x_lo = fwd ? d.ox0 / 2 : 0;
+  d.wown = d.Wi - d.x_lo;
+  const int rows = d.Hi - d.m_lo;
+  const long slots1 = (long)d.B * d.wown;
+  int nb = 1;
+  const long want = 2048L * PPB;
+  if (slots1 < want) {
+    nb = (int)((want + slots1 - 1) / slots1);
+    const int max_nb = rows / 8 > 1 ? rows / 8 : 1;
+    if (nb > max_nb) nb = max_nb;
+  }
+  d.bh = (rows + nb - 1) / nb;
+  d.nb = (rows + d.bh - 1) / d.bh;
+  d.ngroups = (int)(((long)d.B * d.nb * d.wown + PPB - 1) / PPB);
+  grid = d.ngroups < max_blocks ? d.ngroups : max_blocks;
+}
+
 }  // namespace

@@ -238,11 +238,15 @@ def test_first_conv(dev, B, H, W, hp, wp):
     close(dw, w.grad, 1e-4, "wgrad")
 
 
-@pytest.mark.parametrize("B,Hi,Wi,H,W", [(2, 81, 33, 161, 51), (4, 81, 33, 161, 51), (1, 9, 6, 17, 11), (2, 5, 5, 9, 9)])
-def test_last_convT(dev, B, Hi, Wi, H, W):
+@pytest.mark.parametrize("B,Hi,Wi,H,W,C,stride", [
+    (2, 81, 33, 161, 51, 32, (2, 2)), (4, 81, 33, 161, 51, 32, (2, 2)), (1, 9, 6, 17, 11, 32, (2, 2)),
+    (2, 5, 5, 9, 9, 32, (2, 2)), (3, 20, 9, 37, 15, 16, (2, 2)), (2, 11, 7, 20, 13, 64, (2, 2)),
+    # shapes the column walkers do not take: C/4 not a power of two, mixed strides, fewer than 16 channels
+    (2, 9, 6, 17, 9, 24, (2, 2)), (2, 9, 6, 16, 6, 32, (2, 1)), (1, 9, 6, 9, 5, 8, (1, 1)),
+])
+def test_last_convT(dev, B, Hi, Wi, H, W, C, stride):
     from noise_amd import ops
     g = torch.Generator().manual_seed(Hi)
-    C, stride = 32, (2, 2)
     ya, yb = torch.randn(B, C, Hi, Wi, generator=g), torch.randn(B, C, Hi, Wi, generator=g)
     ca, cb = rand_coef(C, g), rand_coef(C, g)
     w = (torch.randn(C, 1, 3, 3, generator=g) * 0.1).requires_grad_(True)
