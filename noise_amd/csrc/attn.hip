@@ -683,10 +683,10 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void attn_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols,
                                                              float* __restrict__ out) {
   __shared__ double red[256];
-  const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int j = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = j < ncols;
   const double s = slab_column_sum(slab, nrows, ncols, j, ok, red);
-  if (threadIdx.x < 32 && ok) out[j] = (float)s;
+  if (threadIdx.x < SLAB_COLS && ok) out[j] = (float)s;
 }
 
 int check_attn(const char* who, long ntok, int n, int d_model, int heads, int dk) {
@@ -795,7 +795,7 @@ NOISE_EXPORT int noise_attn_post_bwd(const float* g3, const float* d_vad, const 
   hipLaunchKernelGGL(attn_post_bwd_kernel, dim3(grid), dim3(256), smem, st, g3, d_vad, o, xhat1, rstd1, hdn, xhat2, rstd2, x3,
                      P, d_o, d_x1, scratch, d);
   NOISE_CHECK_LAUNCH("noise_attn_post_bwd");
-  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, 32)), dim3(256), 0, st, scratch, grid, ncols, grads);
+  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, SLAB_COLS)), dim3(256), 0, st, scratch, grid, ncols, grads);
   NOISE_CHECK_LAUNCH("noise_attn_post_bwd/reduce");
   return 0;
 }
@@ -819,7 +819,7 @@ NOISE_EXPORT int noise_attn_pre_bwd(const float* d_qkv, const float* d_x1, const
   hipLaunchKernelGGL(attn_pre_bwd_kernel, dim3(grid), dim3(256), smem, st, d_qkv, d_x1, xhat0, rstd0, ln_w, ln_b, wq, wk, wv,
                      d_x0, scratch, d);
   NOISE_CHECK_LAUNCH("noise_attn_pre_bwd");
-  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, 32)), dim3(256), 0, st, scratch, grid, ncols, grads);
+  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, SLAB_COLS)), dim3(256), 0, st, scratch, grid, ncols, grads);
   NOISE_CHECK_LAUNCH("noise_attn_pre_bwd/reduce");
   return 0;
 }

@@ -17,11 +17,13 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
                                                               long long* __restrict__ num_batches_tracked, float momentum,
                                                               float eps, float* __restrict__ coef) {
   __shared__ double red[256];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = c < C;
-  const double s1 = slab_column_sum(slab, nrows, 2 * C, c, ok, red);
-  const double s2 = slab_column_sum(slab, nrows, 2 * C, C + c, ok, red);
-  if (threadIdx.x >= 32 || !ok) return;
+  const int cols[2] = {c, C + c};
+  double sums[2];
+  slab_column_sums<2>(slab, nrows, 2 * C, cols, ok, red, sums);
+  const double s1 = sums[0], s2 = sums[1];
+  if (threadIdx.x >= SLAB_COLS || !ok) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -105,11 +107,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef3) {
   __shared__ double red[256];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = c < C;
-  const double s1 = slab_column_sum(slab, nrows, row_stride, c, ok, red);
-  const double s2 = slab_column_sum(slab, nrows, row_stride, C + c, ok, red);
-  if (threadIdx.x >= 32 || !ok) return;
+  const int cols[2] = {c, C + c};
+  double sums[2];
+  slab_column_sums<2>(slab, nrows, row_stride, cols, ok, red, sums);
+  const double s1 = sums[0], s2 = sums[1];
+  if (threadIdx.x >= SLAB_COLS || !ok) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   const double mean = (double)coef[2 * C + c] + (double)coef[4 * C + c], istd = coef[3 * C + c];
@@ -132,7 +136,7 @@ NOISE_EXPORT int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, 
                                        long long* num_batches_tracked, float momentum, float eps, float* coef,
                                        void* stream) {
   NOISE_REQUIRE(slab && gamma && beta && coef && C > 0 && slab_rows > 0 && count > 0, "noise_bn_finalize_fwd: bad argument");
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, slab, slab_rows, C,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(noise_cdiv(C, SLAB_COLS)), dim3(256), 0, (hipStream_t)stream, slab, slab_rows, C,
                      (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, coef);
   NOISE_CHECK_LAUNCH("noise_bn_finalize_fwd");
   return 0;
@@ -160,7 +164,7 @@ NOISE_EXPORT int noise_bn_bwd(const float* g1, const float* g2, const float* y, 
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float), st, g1, g2, y, coef,
                      relu6, C, npix, dz, scratch);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, C, (double)npix,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 2 * C, C, (double)npix,
                      gamma, coef, dgamma, dbeta, coef3);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/finalize");
   return 0;
@@ -173,7 +177,7 @@ NOISE_EXPORT int noise_bn_bwd_finalize(const float* slab, int slab_rows, int row
                                        void* stream) {
   NOISE_REQUIRE(slab && coef && gamma && dgamma && dbeta && coef3 && slab_rows > 0 && row_stride >= 2 * C && npix > 0,
                 "noise_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, slab, slab_rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(noise_cdiv(C, SLAB_COLS)), dim3(256), 0, (hipStream_t)stream, slab, slab_rows,
                      row_stride, C, (double)npix, gamma, coef, dgamma, dbeta, coef3);
   NOISE_CHECK_LAUNCH("noise_bn_bwd_finalize");
   return 0;

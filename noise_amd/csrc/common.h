@@ -101,33 +101,50 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
   return v;
 }
 
-// Column sums of a [nrows][row_stride] fp32 slab in double.  Call with 256 threads laid out as
-// 32 columns x 8 row lanes (col = first_col + (tid & 31), row lane = tid >> 5): reads are 128-byte
-// coalesced and every thread walks nrows/8 rows.  `red` is 256 doubles of LDS; the result is valid in
-// the threads with tid < 32.  Contains barriers: every thread of the block must call it.
+// Column sums of a slab of per-workgroup partials: slab[r][col], r < nrows (row_stride floats apart), in double.
+// A block covers SLAB_COLS columns x (256 / SLAB_COLS) row lanes (col = first_col + (tid & (SLAB_COLS-1)), row
+// lane = tid / SLAB_COLS): a row lane reads 32 contiguous bytes and walks nrows/32 rows, so even a 2048-row slab
+// is only 16 dependent steps of 4 loads deep.  `red` is 256 doubles of LDS per summed column set; the result is
+// valid in the threads with tid < SLAB_COLS.  Contains barriers: every thread of the block must call it.
+#define SLAB_COLS 8
+template <int NSUM>
+__device__ __forceinline__ void slab_column_sums(const float* __restrict__ slab, int nrows, int row_stride,
+                                                 const int (&col)[NSUM], bool col_valid, double* red, double (&out)[NSUM]) {
+  constexpr int LANES = 256 / SLAB_COLS;
+  const int rl = threadIdx.x / SLAB_COLS;
+  double acc[NSUM][4];
+#pragma unroll
+  for (int j = 0; j < NSUM; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0;
+  if (col_valid) {
+    int r = rl;
+    for (; r + 3 * LANES < nrows; r += 4 * LANES) {   // independent chains keep several loads in flight
+#pragma unroll
+      for (int j = 0; j < NSUM; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[j][u] += (double)slab[(size_t)(r + u * LANES) * row_stride + col[j]];
+    }
+    for (; r < nrows; r += LANES)
+#pragma unroll
+      for (int j = 0; j < NSUM; ++j) acc[j][0] += (double)slab[(size_t)r * row_stride + col[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < NSUM; ++j) {
+    __syncthreads();
+    red[threadIdx.x] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x < SLAB_COLS) {
+      for (int k = 0; k < LANES; ++k) s += red[threadIdx.x + SLAB_COLS * k];
+    }
+    out[j] = s;
+  }
+}
+
 __device__ __forceinline__ double slab_column_sum(const float* __restrict__ slab, int nrows, int row_stride, int col,
                                                   bool col_valid, double* red) {
-  const int rl = threadIdx.x >> 5;
-  double s = 0.0;
-  if (col_valid) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep several loads in flight
-    int r = rl;
-    for (; r + 24 < nrows; r += 32) {
-      s0 += (double)slab[(size_t)r * row_stride + col];
-      s1 += (double)slab[(size_t)(r + 8) * row_stride + col];
-      s2 += (double)slab[(size_t)(r + 16) * row_stride + col];
-      s3 += (double)slab[(size_t)(r + 24) * row_stride + col];
-    }
-    for (; r < nrows; r += 8) s0 += (double)slab[(size_t)r * row_stride + col];
-    s = (s0 + s1) + (s2 + s3);
-  }
-  __syncthreads();
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) s += red[threadIdx.x + 32 * k];
-  }
-  return s;
+  const int cols[1] = {col};
+  double out[1];
+  slab_column_sums<1>(slab, nrows, row_stride, cols, col_valid, red, out);
+  return out[0];
 }
 #endif

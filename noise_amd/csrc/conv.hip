@@ -441,10 +441,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           int row_stride, float* __restrict__ out, int tr_k, int tr_C,
                                                           int accumulate) {
   __shared__ double red[256];
-  const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int j = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = j < ncols;
   const double s = slab_column_sum(slab, nrows, row_stride, j, ok, red);
-  if (threadIdx.x >= 32 || !ok) return;
+  if (threadIdx.x >= SLAB_COLS || !ok) return;
   int o = j;
   if (tr_k > 0) {  // j = k*C + c  ->  c*tr_k + k
     const int k = j / tr_C, c = j - k * tr_C;
@@ -570,7 +570,7 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   }
   if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
   return 0;
 }
@@ -605,7 +605,7 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
   hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
                      absmax, scratch, d);
   NOISE_CHECK_LAUNCH("noise_first_conv_wgrad");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_first_conv_wgrad/reduce");
   return 0;
 }
@@ -670,7 +670,7 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
   }
   if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, 32)), dim3(256), 0, st, scratch, grid, 9 * C, 12 * C, dw, 9, C, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 12 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_last_convT_bwd/reduce");
   // the bias gradient sits at slab column 9*C (slot 9, channel 0)
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, scratch + 9 * C, grid, 1, 12 * C, dbias, 0, 0, 0);

@@ -432,10 +432,10 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
 __global__ __launch_bounds__(256) void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols,
                                                              float* __restrict__ out) {
   __shared__ double red[256];
-  const int j = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int j = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = j < ncols;
   const double s = slab_column_sum(slab, nrows, ncols, j, ok, red);
-  if (threadIdx.x < 32 && ok) out[j] = (float)s;
+  if (threadIdx.x < SLAB_COLS && ok) out[j] = (float)s;
 }
 
 template <bool GRAD, int KC, int MT>
@@ -535,7 +535,7 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
 #undef X
   NOISE_REQUIRE(done, "noise_pw_wgrad: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
   NOISE_CHECK_LAUNCH("noise_pw_wgrad");
-  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 32)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
+  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, SLAB_COLS)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
   NOISE_CHECK_LAUNCH("noise_pw_wgrad/reduce");
   return 0;
 }
@@ -586,7 +586,7 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
 #undef X
   NOISE_REQUIRE(done, "noise_pw_bwd: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
   NOISE_CHECK_LAUNCH("noise_pw_bwd");
-  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, 32)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
+  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, SLAB_COLS)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
   NOISE_CHECK_LAUNCH("noise_pw_bwd/reduce");
   return 0;
 }
