@@ -272,11 +272,19 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
     ecf[3 * KP + k] = in ? E.coef[3 * K + k] : 1.f;
     ecf[4 * KP + k] = in ? E.coef[4 * K + k] : 0.f;
   }
-  f32x4 acc[KC][MTI];
+  // weight gradient: the KC x MTI tiles of dW are dealt round-robin to the four waves (tile t = m*MTI + n belongs to
+  // wave t % 4); a wave runs all 64 pixels of a staged tile through its own dW tiles, so no cross-wave sum is needed
+  constexpr int T = KC * MTI, TPW = (T + 3) / 4;
+  f32x4 acc[TPW];
 #pragma unroll
-  for (int m = 0; m < KC; ++m)
+  for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int dyo[TPW], avo[TPW];   // LDS offsets of this wave's tiles: dys column 16*m + p, as column 16*n + p
 #pragma unroll
-    for (int n = 0; n < MTI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < TPW; ++j) {
+    const int t = wave + 4 * j, m = t / MTI, n = t - m * MTI;
+    dyo[j] = 16 * m + p;
+    avo[j] = 16 * n + p;
+  }
   float4 s1[MTI], s2[MTI];
 #pragma unroll
   for (int m = 0; m < MTI; ++m) s1[m] = s2[m] = f4(0.f);
@@ -359,19 +367,15 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
         }
       }
     }
-    // ---- wgrad: 4 k-steps of 4 pixels
+    // ---- wgrad: 16 k-steps of 4 pixels over this wave's tiles
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int pp = 4 * s + q;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int pp = 16 * wave + 4 * s + q;
-      float dy[KC], av[MTI];
-#pragma unroll
-      for (int m = 0; m < KC; ++m) dy[m] = dys[pp * pn + 16 * m + p];
-#pragma unroll
-      for (int n = 0; n < MTI; ++n) av[n] = as[pp * pk + 16 * n + p];
-#pragma unroll
-      for (int m = 0; m < KC; ++m)
-#pragma unroll
-        for (int n = 0; n < MTI; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[m], av[n], acc[m][n], 0, 0, 0);
+      for (int j = 0; j < TPW; ++j) {
+        if (wave + 4 * j < T)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
+      }
     }
   }
 
@@ -405,24 +409,20 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
     }
     __syncthreads();
   }
-  // ---- dW: D layout col = ci0 + (lane&15), rows = co0 + 4*(lane>>4) + reg; fold the four waves through LDS
-  for (int wv = 0; wv < 4; ++wv) {
-    __syncthreads();
-    if (wave == wv) {
+  // ---- dW: D layout col = ci0 + (lane&15), rows = co0 + 4*(lane>>4) + reg; every tile has one owner, so the waves
+  // drop their tiles into LDS side by side and the block writes the slab row with coalesced stores
+  __syncthreads();
 #pragma unroll
-      for (int m = 0; m < KC; ++m)
+  for (int j = 0; j < TPW; ++j) {
+    const int t = wave + 4 * j;
+    if (t < T) {
+      const int m = t / MTI, n = t - m * MTI;
+      const int ci = 16 * n + p;
 #pragma unroll
-        for (int n = 0; n < MTI; ++n) {
-          const int ci = 16 * n + p;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int co = 16 * m + 4 * q + e;
-            if (co < N && ci < K) {
-              float* dst = lds + co * K + ci;
-              *dst = (wv == 0) ? acc[m][n][e] : *dst + acc[m][n][e];
-            }
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int co = 16 * m + 4 * q + e;
+        if (co < N && ci < K) lds[co * K + ci] = acc[j][e];
+      }
     }
   }
   __syncthreads();
