@@ -245,8 +245,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, La
 //   dW[co][ci] += sum_p dy[p][co] a[p][ci]
 // KC = ceil(N/16) (N = Cout), MTI = ceil(K/16) (K = Cin).  64 pixels per workgroup iteration are staged in LDS
 // (dy with the lazy BatchNorm backward applied, a with the lazy activation applied); each wave owns 16 of them.
+// LDS of one workgroup (floats) and the number of workgroups a CU can hold by that measure (at most 3-4): the register
+// budget is pinned to the same occupancy, otherwise the scheduler hoists every staged load and halves it.
+constexpr int pw_bwd_lds_floats(int KC, int MTI) {
+  return MTI * KC * 256 + WG_TILE * (KC * 16 + 4) + WG_TILE * (MTI * 16 + 4) + 5 * MTI * 16;
+}
+constexpr int pw_bwd_min_blocks(int KC, int MTI) {
+  const int b = 160 * 1024 / (pw_bwd_lds_floats(KC, MTI) * 4);
+  const int cap = KC * MTI <= 3 ? 4 : 3;   // 128 registers only fit the smallest tiles without spilling
+  return b > cap ? cap : (b < 1 ? 1 : b);
+}
+
 template <int KC, int MTI>
-__global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bs, const float* __restrict__ W,
+__global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bs, const float* __restrict__ W,
                                                      float* __restrict__ g_in, BwdEpilogue E, float* __restrict__ dw_slab,
                                                      long npix, int N, int K) {
   extern __shared__ float lds[];
@@ -289,42 +300,97 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
 #pragma unroll
   for (int m = 0; m < MTI; ++m) s1[m] = s2[m] = f4(0.f);
 
+  // Staging map: a thread keeps one group of 4 channels for every row it stages (rows rn, rn + RN, ... of the
+  // 64-pixel tile), so the per-channel coefficients of the lazy transforms are loaded once, into registers.
+  constexpr int CGN = NP / 4, RN = 256 / CGN, PASS_N = (WG_TILE + RN - 1) / RN;
+  constexpr int CGK = KP / 4, RK = 256 / CGK, PASS_K = (WG_TILE + RK - 1) / RK;
+  const int rn = tid / CGN, cn = (tid - rn * CGN) * 4;
+  const int rk = tid / CGK, ck = (tid - rk * CGK) * 4;
+  const bool on = rn < RN && cn < N, ok = rk < RK && ck < K;
+  float4 gs = f4(1.f), gk1h = f4(0.f), gk1l = f4(0.f), ga2 = f4(0.f), gmh = f4(0.f), gml = f4(0.f);
+  if (on && G.coef3) {
+    gs = ld4(G.coef3 + cn);
+    gk1h = ld4(G.coef3 + N + cn);
+    gk1l = ld4(G.coef3 + 2 * N + cn);
+    ga2 = ld4(G.coef3 + 3 * N + cn);
+    gmh = ld4(G.coef3 + 4 * N + cn);
+    gml = ld4(G.coef3 + 5 * N + cn);
+  }
+  float4 asc = f4(1.f), ash = f4(0.f), bsc = f4(1.f), bsh = f4(0.f);
+  if (ok && A.coef) {
+    asc = ld4(A.coef + ck);
+    ash = ld4(A.coef + K + ck);
+  }
+  if (ok && Bs.y && Bs.coef) {
+    bsc = ld4(Bs.coef + ck);
+    bsh = ld4(Bs.coef + K + ck);
+  }
+
   const long ntiles = (npix + WG_TILE - 1) / WG_TILE;
   const long iters = (ntiles + gridDim.x - 1) / gridDim.x;
   for (long it = 0; it < iters; ++it) {
     const long tile = (long)blockIdx.x + it * gridDim.x;
     const long pix0 = tile * WG_TILE;
+    const long left = tile < ntiles ? npix - pix0 : 0;   // valid rows of this tile
     __syncthreads();
-    for (int e = tid; e < WG_TILE * (NP / 4); e += 256) {
-      const int pp = e / (NP / 4), c = (e - pp * (NP / 4)) * 4;
-      float4 v = f4(0.f);
-      if (tile < ntiles && pix0 + pp < npix && c < N) {
-        const size_t off = (size_t)(pix0 + pp) * N + c;
-        v = ld4(G.dz + off);
-        if (G.coef3) {
-          const float4 t1 = sub4(sub4(v, ld4(G.coef3 + N + c)), ld4(G.coef3 + 2 * N + c));
-          const float4 t2 = sub4(sub4(ld4(G.y + off), ld4(G.coef3 + 4 * N + c)), ld4(G.coef3 + 5 * N + c));
-          v = fma4(ld4(G.coef3 + 3 * N + c), t2, ld4(G.coef3 + c) * t1);
+    // loads are issued in batches of up to 4 rows per thread from clamped (always valid) addresses, then
+    // transformed and stored: the memory latency is paid once per batch, not once per row
+    if (rn < RN) {
+      const int cnc = on ? cn : 0;
+#pragma unroll
+      for (int ps0 = 0; ps0 < PASS_N; ps0 += 4) {
+        float4 rz[4], ry[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ps0 + u < PASS_N) {
+            long pix = pix0 + rn + (ps0 + u) * RN;
+            pix = pix < npix ? pix : npix - 1;
+            const size_t off = (size_t)pix * N + cnc;
+            rz[u] = ld4(G.dz + off);
+            ry[u] = G.coef3 ? ld4(G.y + off) : f4(0.f);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = rn + (ps0 + u) * RN;
+          if (ps0 + u < PASS_N && pp < WG_TILE) {
+            float4 v = rz[u];
+            if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
+            st4(dys + pp * pn + cn, (on && pp < left) ? v : f4(0.f));
+          }
         }
       }
-      st4(dys + pp * pn + c, v);
     }
-    for (int e = tid; e < WG_TILE * (KP / 4); e += 256) {
-      const int pp = e / (KP / 4), c = (e - pp * (KP / 4)) * 4;
-      float4 v = f4(0.f);
-      if (tile < ntiles && pix0 + pp < npix && c < K) {
-        const size_t off = (size_t)(pix0 + pp) * K + c;
-        v = ld4(A.y + off);
-        if (A.coef) v = fma4(v, ld4(A.coef + c), ld4(A.coef + K + c));
-        if (A.relu6) v = relu6_4(v);
-        if (Bs.y) {
-          float4 u = ld4(Bs.y + off);
-          if (Bs.coef) u = fma4(u, ld4(Bs.coef + c), ld4(Bs.coef + K + c));
-          if (Bs.relu6) u = relu6_4(u);
-          v = v + u;
+    if (rk < RK) {
+      const int ckc = ok ? ck : 0;
+#pragma unroll
+      for (int ps0 = 0; ps0 < PASS_K; ps0 += 4) {
+        float4 ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ps0 + u < PASS_K) {
+            long pix = pix0 + rk + (ps0 + u) * RK;
+            pix = pix < npix ? pix : npix - 1;
+            const size_t off = (size_t)pix * K + ckc;
+            ra[u] = ld4(A.y + off);
+            rb[u] = Bs.y ? ld4(Bs.y + off) : f4(0.f);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = rk + (ps0 + u) * RK;
+          if (ps0 + u < PASS_K && pp < WG_TILE) {
+            float4 v = fma4(ra[u], asc, ash);
+            if (A.relu6) v = relu6_4(v);
+            if (Bs.y) {
+              float4 w2 = fma4(rb[u], bsc, bsh);
+              if (Bs.relu6) w2 = relu6_4(w2);
+              v = v + w2;
+            }
+            st4(as + pp * pk + ck, (ok && pp < left) ? v : f4(0.f));
+          }
         }
       }
-      st4(as + pp * pk + c, v);
     }
     __syncthreads();
     // ---- dgrad for this wave's 16 pixels
@@ -368,7 +434,7 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
       }
     }
     // ---- wgrad: 16 k-steps of 4 pixels over this wave's tiles
-#pragma unroll 4
+#pragma unroll 2
     for (int s = 0; s < 16; ++s) {
       const int pp = 4 * s + q;
 #pragma unroll
