@@ -69,8 +69,11 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
   const float* bas = basisT + n;
+  int rtc[NT];
+#pragma unroll
+  for (int r = 0; r < NT; ++r) rtc[r] = 32 * (wave + 4 * r < nRT ? wave + 4 * r : nRT - 1);
   for (int c = 0; c < R; ++c) {
-#pragma unroll 4
+#pragma unroll 8
     for (int kq = 0; kq < hop; kq += 2) {
       const int kk = c * hop + kq + h;
       const float b0 = lds[n * pitch + kk + c];
@@ -78,12 +81,11 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(
       const float* arow = bas + (size_t)kk * d.Rpad;
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
-        const int rt = wave + 4 * r;
-        if (rt < nRT) {
-          const float a = arow[rt * 32];
-          acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[r][0], 0, 0, 0);
-          acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[r][1], 0, 0, 0);
-        }
+        // branch-free: a wave without an r-th row tile recomputes its last one (discarded in the epilogue), so the
+        // basis loads of later steps can be issued ahead of the MFMAs of this one
+        const float a = arow[rtc[r]];
+        acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[r][0], 0, 0, 0);
+        acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[r][1], 0, 0, 0);
       }
     }
   }
@@ -171,15 +173,15 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ lo
     for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
   const float* bas = inv_basis + (size_t)h * F * n_fft + n;
+  int ntc[NT];   // branch-free row tiles, see stft_frames_kernel
+#pragma unroll
+  for (int r = 0; r < NT; ++r) ntc[r] = 32 * (wave + 4 * r < nNT ? wave + 4 * r : nNT - 1);
 #pragma unroll 4
   for (int f = 0; f < F; ++f) {
     const float bv = lds[(2 * f + h) * 32 + n];
     const float* arow = bas + (size_t)f * n_fft;
 #pragma unroll
-    for (int r = 0; r < NT; ++r) {
-      const int nt = wave + 4 * r;
-      if (nt < nNT) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[nt * 32], bv, acc[r], 0, 0, 0);
-    }
+    for (int r = 0; r < NT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[ntc[r]], bv, acc[r], 0, 0, 0);
   }
   __syncthreads();
 
