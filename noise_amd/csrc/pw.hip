@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
   int dyo[TPW], avo[TPW];   // LDS offsets of this wave's tiles: dys column 16*m + p, as column 16*n + p
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
-    const int t = wave + 4 * j, m = t / MTI, n = t - m * MTI;
+    // a wave without a j-th tile recomputes its first one into an accumulator that is never written back: the
+    // k-loop below then has no branches and its LDS reads can run ahead of the MFMAs
+    const int t = wave + 4 * j < T ? wave + 4 * j : wave % T, m = t / MTI, n = t - m * MTI;
     dyo[j] = 16 * m + p;
     avo[j] = 16 * n + p;
   }
@@ -397,6 +399,19 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     if (g_in != nullptr) {
       const long pix = pix0 + 16 * wave + p;
       const bool valid = tile < ntiles && pix < npix;
+      const size_t prow = (size_t)(pix < npix ? pix : npix - 1) * K;
+      // what the epilogue needs from memory is requested before the MFMA chains (clamped, always valid addresses)
+      // when the registers allow it (few input-channel tiles), otherwise tile by tile
+      constexpr bool PRE = MTI <= 3;
+      float4 yr[PRE ? MTI : 1], go[PRE ? MTI : 1];
+      if (PRE) {
+#pragma unroll
+        for (int m = 0; m < MTI; ++m) {
+          const int ci = 16 * m + 4 * q, cic = ci < K ? ci : 0;
+          yr[m] = E.coef ? ld4(A.y + prow + cic) : f4(0.f);
+          go[m] = E.g_other ? ld4(E.g_other + prow + cic) : f4(0.f);
+        }
+      }
       float4 in[KC];
 #pragma unroll
       for (int jj = 0; jj < KC; ++jj) in[jj] = ld4(dys + (16 * wave + p) * pn + 16 * jj + 4 * q);
@@ -413,11 +428,11 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
         }
         const int ci = 16 * m + 4 * q;
         if (valid && ci < K) {
-          const size_t off = (size_t)pix * K + ci;
+          const size_t off = prow + ci;
           float4 g = make_float4(o[0], o[1], o[2], o[3]);
-          if (E.g_other) g = g + ld4(E.g_other + off);
+          if (E.g_other) g = g + (PRE ? go[m] : ld4(E.g_other + off));
           if (E.coef) {
-            const float4 yraw = ld4(A.y + off);
+            const float4 yraw = PRE ? yr[m] : ld4(A.y + off);
             if (E.relu6) {
               const float4 v = fma4(yraw, ld4(ecf + ci), ld4(ecf + KP + ci));
               g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
@@ -438,10 +453,8 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     for (int s = 0; s < 16; ++s) {
       const int pp = 4 * s + q;
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        if (wave + 4 * j < T)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < TPW; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
     }
   }
 
