@@ -583,11 +583,18 @@ NOISE_EXPORT int noise_first_conv_fwd(const float* logmag, const float* absmax, 
   NOISE_REQUIRE(logmag && absmax && w && out, "noise_first_conv_fwd: null pointer");
   FirstDims d{B, H, W, hp, wp, (H + hp - 1) / sy + 1, (W + wp - 1) / sx + 1, C, sy, sx, pad_value};
   if (check_size("noise_first_conv_fwd", (long)B * (H + hp) * (W + wp), C)) return -1;
-  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
+  int grid = conv_grid((long)B * d.Ho * d.Wo, C);
   const int PPB = 256 / (C / 4);
+  if (sy == 2 && sx == 2) {
+    FirstWalkDims wd{B, H, W, hp, wp, d.Ho, d.Wo, C, pad_value, 0, 0, 0};
+    first_walk_plan(wd, noise_conv_max_blocks(), grid);
+    hipLaunchKernelGGL(first_walk_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
+                       (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
+  } else {
+    hipLaunchKernelGGL(first_conv_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
+                       (hipStream_t)stream, logmag, absmax, w, out, stats_slab, d);
+  }
   if (slab_rows) *slab_rows = grid;
-  hipLaunchKernelGGL(first_conv_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
-                     (hipStream_t)stream, logmag, absmax, w, out, stats_slab, d);
   NOISE_CHECK_LAUNCH("noise_first_conv_fwd");
   return 0;
 }
@@ -599,11 +606,18 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
   NOISE_REQUIRE(dz && logmag && absmax && dw && scratch, "noise_first_conv_wgrad: null pointer");
   FirstDims d{B, H, W, hp, wp, (H + hp - 1) / sy + 1, (W + wp - 1) / sx + 1, C, sy, sx, pad_value};
   LazyGrad G{dz, y_out, coef3};
-  const int grid = conv_grid((long)B * d.Ho * d.Wo, C);
+  int grid = conv_grid((long)B * d.Ho * d.Wo, C);
   const int PPB = 256 / (C / 4);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
-                     absmax, scratch, d);
+  if (sy == 2 && sx == 2) {
+    FirstWalkDims wd{B, H, W, hp, wp, d.Ho, d.Wo, C, pad_value, 0, 0, 0};
+    first_walk_plan(wd, noise_conv_max_blocks(), grid);
+    hipLaunchKernelGGL(first_walk_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
+                       absmax, scratch, wd);
+  } else {
+    hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
+                       absmax, scratch, d);
+  }
   NOISE_CHECK_LAUNCH("noise_first_conv_wgrad");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 9 * C, dw, 9, C, 0);
   NOISE_CHECK_LAUNCH("noise_first_conv_wgrad/reduce");

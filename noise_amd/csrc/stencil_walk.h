@@ -582,3 +582,143 @@ inline void last_walk_plan(LastWalkDims& d, bool fwd, int max_blocks, int& grid)
 }
 
 }  // namespace
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// First layer (train/models.py:1151-1159 on the input padded by :589 and normalised by :614-622), stride 2:
+// gather geometry over a single-channel input, so the 3x3 window is nine scalars shared by the channel lanes.
+//   x_in(py, px) = 0 outside the padded input, pad_value inside the F.pad border, logmag / max elsewhere
+struct FirstWalkDims {
+  int B, H, W, hp, wp, Ho, Wo, C;
+  float pad_value;
+  int nb, bh, ngroups;
+};
+
+struct FirstWindow {
+  const float* x;   // this clip's log-magnitudes (H, W)
+  float mx;         // per-clip max + 1e-6 (divided, as the reference does)
+  int H, W, hp, wp;
+  float pad_value;
+  int px0;          // padded column of tap kx = 0
+  __device__ __forceinline__ void row(int py, float (&r)[3]) const {   // py: padded row; branch-free
+    const int y = py - hp;
+    const bool rin = py >= 0 && py < H + hp, rdata = y >= 0 && rin;
+    const float* xr = x + (size_t)(rdata ? y : 0) * W;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int px = px0 + j, xx = px - wp;
+      const bool cin = px >= 0 && px < W + wp, cdata = xx >= 0 && cin;
+      const float v = xr[cdata ? xx : 0] / mx;
+      r[j] = (rin && cin) ? ((rdata && cdata) ? v : pad_value) : 0.f;
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void first_walk_fwd_kernel(const float* __restrict__ x, const float* __restrict__ absmax,
+                                                             const float* __restrict__ w, float* __restrict__ out,
+                                                             float* __restrict__ slab, FirstWalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (pl < PPB) {
+    float4 wk[9];
+    load_taps(w, c, false, wk);
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      const int slot = g * PPB + pl;
+      if (slot >= d.B * d.nb * d.Wo) continue;
+      const int ox = slot % d.Wo;
+      const int u = slot / d.Wo;
+      const int band = u % d.nb, bi = u / d.nb;
+      const int r0 = band * d.bh, r1 = r0 + d.bh < d.Ho ? r0 + d.bh : d.Ho;
+      const FirstWindow win{x + (size_t)bi * d.H * d.W, absmax[bi] + 1e-6f, d.H, d.W, d.hp, d.wp, d.pad_value,
+                            2 * ox - 1};
+      float t0[3], t1[3], t2[3];
+      win.row(2 * r0 - 1, t0);
+      float* o = out + (((size_t)bi * d.Ho + r0) * d.Wo + ox) * C + c;
+      for (int oy = r0; oy < r1; ++oy, o += (size_t)d.Wo * C) {
+        win.row(2 * oy, t1);
+        win.row(2 * oy + 1, t2);
+        float4 acc = f4(t0[0]) * wk[0];
+        acc = fma4(f4(t0[1]), wk[1], acc);
+        acc = fma4(f4(t0[2]), wk[2], acc);
+        acc = fma4(f4(t1[0]), wk[3], acc);
+        acc = fma4(f4(t1[1]), wk[4], acc);
+        acc = fma4(f4(t1[2]), wk[5], acc);
+        acc = fma4(f4(t2[0]), wk[6], acc);
+        acc = fma4(f4(t2[1]), wk[7], acc);
+        acc = fma4(f4(t2[2]), wk[8], acc);
+        st4(o, acc);
+        s1 = s1 + acc;
+        s2 = fma4(acc, acc, s2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t0[j] = t2[j];
+      }
+    }
+  }
+  if (slab != nullptr) {
+    const float4 v[2] = {s1, s2};
+    block_channel_reduce<2>(v, C, CG, PPB, red, slab + (size_t)blockIdx.x * 2 * C);
+  }
+}
+
+// dW[c][k] = sum_o dy[o][c] * x_in(2o - 1 + k)   (the input is data: no input gradient)
+__global__ __launch_bounds__(256) void first_walk_wgrad_kernel(LazyGrad G, const float* __restrict__ x,
+                                                               const float* __restrict__ absmax,
+                                                               float* __restrict__ dw_slab, FirstWalkDims d) {
+  extern __shared__ float red[];
+  const int C = d.C, CG = C >> 2, PPB = 256 / CG;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  float4 dwk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dwk[k] = f4(0.f);
+  if (pl < PPB) {
+    const LazyGrad4 gr = lazygrad4_init(G, C, c);
+    for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
+      const int slot = g * PPB + pl;
+      if (slot >= d.B * d.nb * d.Wo) continue;
+      const int ox = slot % d.Wo;
+      const int u = slot / d.Wo;
+      const int band = u % d.nb, bi = u / d.nb;
+      const int r0 = band * d.bh, r1 = r0 + d.bh < d.Ho ? r0 + d.bh : d.Ho;
+      const FirstWindow win{x + (size_t)bi * d.H * d.W, absmax[bi] + 1e-6f, d.H, d.W, d.hp, d.wp, d.pad_value,
+                            2 * ox - 1};
+      float t0[3], t1[3], t2[3];
+      win.row(2 * r0 - 1, t0);
+      size_t off = (((size_t)bi * d.Ho + r0) * d.Wo + ox) * C + c;
+      for (int oy = r0; oy < r1; ++oy, off += (size_t)d.Wo * C) {
+        win.row(2 * oy, t1);
+        win.row(2 * oy + 1, t2);
+        const float4 dy = lazygrad4_at(gr, off);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dwk[j] = fma4(dy, f4(t0[j]), dwk[j]);
+          dwk[3 + j] = fma4(dy, f4(t1[j]), dwk[3 + j]);
+          dwk[6 + j] = fma4(dy, f4(t2[j]), dwk[6 + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t0[j] = t2[j];
+      }
+    }
+  }
+  block_channel_reduce<9>(dwk, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 9 * C);
+}
+
+inline void first_walk_plan(FirstWalkDims& d, int max_blocks, int& grid) {
+  const int PPB = 256 / (d.C / 4);
+  const long slots1 = (long)d.B * d.Wo;
+  int nb = 1;
+  const long want = 2048L * PPB;
+  if (slots1 < want) {
+    nb = (int)((want + slots1 - 1) / slots1);
+    const int max_nb = d.Ho / 8 > 1 ? d.Ho / 8 : 1;
+    if (nb > max_nb) nb = max_nb;
+  }
+  d.bh = (d.Ho + nb - 1) / nb;
+  d.nb = (d.Ho + d.bh - 1) / d.bh;
+  d.ngroups = (int)(((long)d.B * d.nb * d.Wo + PPB - 1) / PPB);
+  grid = d.ngroups < max_blocks ? d.ngroups : max_blocks;
+}
+
+}  // namespace

@@ -212,11 +212,14 @@ def test_pointwise(dev, K, N, npix, two_src):
     close(g_in, a_in.grad, msg="fused dgrad, no epilogue")
 
 
-@pytest.mark.parametrize("B,H,W,hp,wp", [(2, 161, 51, 0, 14), (1, 33, 20, 3, 5), (3, 17, 17, 0, 0)])
-def test_first_conv(dev, B, H, W, hp, wp):
+@pytest.mark.parametrize("B,H,W,hp,wp,C,stride", [
+    (2, 161, 51, 0, 14, 32, (2, 2)), (1, 33, 20, 3, 5, 32, (2, 2)), (3, 17, 17, 0, 0, 32, (2, 2)),
+    (4, 161, 51, 0, 14, 32, (2, 2)), (2, 30, 22, 2, 1, 48, (2, 2)),
+    (2, 33, 20, 3, 5, 16, (2, 1)), (2, 12, 9, 1, 0, 8, (1, 1)),     # mixed / unit strides: the generic kernels
+])
+def test_first_conv(dev, B, H, W, hp, wp, C, stride):
     from noise_amd import ops
     g = torch.Generator().manual_seed(H)
-    C, stride = 32, (2, 2)
     lm = torch.randn(B, 1, H, W, generator=g) * 3
     mx = lm.abs().reshape(B, -1).max(1)[0]
     w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).requires_grad_(True)
