@@ -154,7 +154,7 @@ int noise_loss_max_blocks(void);
 int noise_spectral_l1(const float* enh, const float* clean_logmag, float* d_enh, double* partial, int* n_partial,
                       long n, void* stream);                                          /* :777 */
 int noise_vad_label(const float* clean, float* label, int B, int L, int min_active, void* stream);   /* :782 */
-/* l1_loss((B,1,1,L),(B,L)) broadcasts to all (i,j) clip pairs (:786-787); partial: ceil(L/4) doubles */
+/* l1_loss((B,1,1,L),(B,L)) broadcasts to all (i,j) clip pairs (:786-787); partial: ceil(L/2) doubles */
 int noise_wave_pair_l1(const float* wave, const float* clean, float* d_wave, double* partial, int* n_partial,
                        int B, int L, void* stream);
 /* out4 = [loss, vad_loss, waveform_loss, spectral_loss] (:790-797); d_vad = dBCE/dlogit (:780-783) */

@@ -121,18 +121,20 @@ __global__ __launch_bounds__(256) void wave_pair_sorted_kernel(const float* __re
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t0 = blockIdx.x * WTS;
+  // NP and WTS are powers of two: every index split below is a shift / mask
+  const int lw = __ffs(WTS) - 1, lh = __ffs(NP) - 2;
   for (int e = tid; e < WTS * NP; e += 256) {
-    const int tt = e % WTS, j = e / WTS;
+    const int tt = e & (WTS - 1), j = e >> lw;
     cs[tt * NP + j] = (j < B && t0 + tt < L) ? c[(size_t)j * L + t0 + tt] : INFINITY;
   }
   __syncthreads();
   // bitonic sort of each row (ascending)
   const int half = NP >> 1;
   for (int k = 2; k <= NP; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int j = k >> 1, lj = __ffs(k) - 2; j > 0; j >>= 1, --lj) {
       for (int e = tid; e < WTS * half; e += 256) {
-        const int row = e / half, p = e - row * half;
-        const int lo = 2 * j * (p / j) + (p % j), hi = lo + j;
+        const int row = e >> lh, p = e & (half - 1);
+        const int lo = ((p >> lj) << (lj + 1)) + (p & (j - 1)), hi = lo + j;
         float* r = cs + row * NP;
         const float a = r[lo], b = r[hi];
         const bool up = (lo & k) == 0;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void wave_pair_sorted_kernel(const float* __re
   __syncthreads();
   double total = 0.0;
   for (int e = tid; e < B * WTS; e += 256) {
-    const int tt = e % WTS, i = e / WTS;
+    const int tt = e & (WTS - 1), i = e >> lw;
     const int t = t0 + tt;
     if (t >= L) continue;
     const float wv = w[(size_t)i * L + t];
@@ -255,19 +257,19 @@ NOISE_EXPORT int noise_vad_label(const float* clean, float* label, int B, int L,
   return 0;
 }
 
-// Cross-pair waveform L1 (the reference's broadcast).  partial: at least ceil(L/4) doubles.
+// Cross-pair waveform L1 (the reference's broadcast).  partial: at least ceil(L/2) doubles.
 NOISE_EXPORT int noise_wave_pair_l1(const float* wave, const float* clean, float* d_wave, double* partial, int* n_partial,
                                     int B, int L, void* stream) {
   NOISE_REQUIRE(wave && clean && partial && B > 0 && L > 0, "noise_wave_pair_l1: bad argument");
   if (B >= 64 && B <= 2048) {   // sorted algorithm: B log B instead of B^2 per time sample
     int NP = 64;
     while (NP < B) NP <<= 1;
+    // columns per workgroup: the kernel is a chain of barriers and dependent LDS reads, so several small
+    // workgroups per CU (<= 40 KiB of LDS each) hide far more latency than one large one
+    const size_t per_col = (size_t)(B + 1) * sizeof(double) + (size_t)NP * sizeof(float);
     int WTS = 8;
-    size_t smem = (size_t)WTS * ((size_t)(B + 1) * sizeof(double) + (size_t)NP * sizeof(float));
-    if (smem > 150 * 1024) {
-      WTS = 4;
-      smem = (size_t)WTS * ((size_t)(B + 1) * sizeof(double) + (size_t)NP * sizeof(float));
-    }
+    while (WTS > 2 && WTS * per_col > 40 * 1024) WTS >>= 1;
+    const size_t smem = WTS * per_col;
     const int grid = noise_cdiv(L, WTS);
     if (n_partial) *n_partial = grid;
     const double cnt = (double)B * (double)B * (double)L;

@@ -399,7 +399,7 @@ class VADSpectralV2(_LightningModule):
             bufs = dict(label=torch.empty(B, device=dev), d_enh=torch.empty(B, H, W, device=dev),
                         d_wave=torch.empty(B, seg, device=dev), d_vad=torch.empty(B, device=dev),
                         spec_partial=torch.empty(LOSS_MAX_BLOCKS, device=dev, dtype=torch.float64),
-                        wave_partial=torch.empty((seg + 3) // 4, device=dev, dtype=torch.float64),
+                        wave_partial=torch.empty((seg + 1) // 2, device=dev, dtype=torch.float64),
                         out4=torch.empty(4, device=dev))
             self._step_bufs[key] = bufs
         import ctypes

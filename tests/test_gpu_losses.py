@@ -35,7 +35,7 @@ def test_wave_pair_l1(dev, B, L):
     ref.backward()
     wd, cd = w.to(dev), c.to(dev)
     d_w = torch.empty(B, L, device=dev)
-    partial = torch.zeros((L + 3) // 4 + 8, dtype=torch.float64, device=dev)
+    partial = torch.zeros((L + 1) // 2 + 8, dtype=torch.float64, device=dev)
     n = ctypes.c_int(0)
     _lib.call("noise_wave_pair_l1", ptr(wd), ptr(cd), ptr(d_w), ptr(partial), ctypes.byref(n), B, L, _lib.stream())
     got = partial[: n.value].sum().item() / (B * B * L)
