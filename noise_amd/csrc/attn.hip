@@ -314,6 +314,199 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// B': the same core for clips of at most 64 tokens (the training segments: 55): one WAVE per (clip, head), lane =
+// query (phase 1) or key (phase 2).  A lane keeps its whole row of attention weights in registers, so the
+// scores are computed once, K / V / Q / dO rows are read from LDS as float4 broadcasts (rows padded to DK4*4
+// floats), and the backward pass hands p and ds from the query lanes to the key lanes through one n x n LDS
+// matrix instead of recomputing them.  Summation orders are those of the kernels above.
+constexpr int AW = 64;
+
+template <int DK4>
+__device__ __forceinline__ float dot_row(const float (&a)[DK4 * 4], const float* row) {
+  float s = 0.f;
+#pragma unroll
+  for (int c4 = 0; c4 < DK4; ++c4) {
+    const float4 k = ld4(row + 4 * c4);
+    s = fmaf(a[4 * c4 + 0], k.x, s);
+    s = fmaf(a[4 * c4 + 1], k.y, s);
+    s = fmaf(a[4 * c4 + 2], k.z, s);
+    s = fmaf(a[4 * c4 + 3], k.w, s);
+  }
+  return s;
+}
+
+template <int DK4>
+__device__ __forceinline__ void axpy_row(float a, const float* row, float (&acc)[DK4 * 4]) {
+#pragma unroll
+  for (int c4 = 0; c4 < DK4; ++c4) {
+    const float4 v = ld4(row + 4 * c4);
+    acc[4 * c4 + 0] = fmaf(a, v.x, acc[4 * c4 + 0]);
+    acc[4 * c4 + 1] = fmaf(a, v.y, acc[4 * c4 + 1]);
+    acc[4 * c4 + 2] = fmaf(a, v.z, acc[4 * c4 + 2]);
+    acc[4 * c4 + 3] = fmaf(a, v.w, acc[4 * c4 + 3]);
+  }
+}
+
+// stage rows [n][dk] of one head (column offset col0 of a row-major matrix with row stride ld) as [n][DK4*4]
+template <int DK4>
+__device__ __forceinline__ void stage_head(float* dst, const float* __restrict__ src, long base, int ld, int col0, int n,
+                                           int dk, float scale_div) {
+  constexpr int DKP = DK4 * 4;
+  for (int i = threadIdx.x; i < n * DKP; i += AW) {
+    const int j = i / DKP, c = i - j * DKP;
+    float v = 0.f;
+    if (c < dk) {
+      v = src[(base + j) * ld + col0 + c];
+      if (scale_div != 0.f) v = v / scale_div;
+    }
+    dst[i] = v;
+  }
+}
+
+template <int DK4>
+__global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                float* __restrict__ ml,
+                                                                const unsigned char* __restrict__ keep,
+                                                                unsigned long long seed, float p_drop, AttnDims d) {
+  extern __shared__ float lds[];
+  constexpr int DKP = DK4 * 4;
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+  float* ks = lds;             // [n][DKP]
+  float* vs = ks + n * DKP;    // [n][DKP]
+  const long base = (long)b * n;
+  stage_head<DK4>(ks, qkv, base, O, d.hd + h * dk, n, dk, 0.f);
+  stage_head<DK4>(vs, qkv, base, O, 2 * d.hd + h * dk, n, dk, 0.f);
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const float temp = sqrtf((float)dk);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  float q[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) q[c] = c < dk ? qkv[(base + i) * O + h * dk + c] / temp : 0.f;
+  float s[AW];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < AW; ++j) {
+    if (j < n) {
+      s[j] = dot_row<DK4>(q, ks + j * DKP);
+      m = fmaxf(m, s[j]);
+    }
+  }
+  float l = 0.f, acc[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) acc[c] = 0.f;
+  const long mrow = (((long)b * d.heads + h) * n + i) * n;
+#pragma unroll
+  for (int j = 0; j < AW; ++j) {
+    if (j < n) {
+      const float e = expf(s[j] - m);
+      l += e;
+      if (keep_elem(keep, seed, p_drop, mrow + j)) axpy_row<DK4>(e, vs + j * DKP, acc);
+    }
+  }
+  const float sc = inv_keep / l;
+#pragma unroll
+  for (int c = 0; c < DKP; ++c)
+    if (c < dk) o[(base + i) * d.hd + h * dk + c] = acc[c] * sc;
+  if (ml) {
+    ml[(((long)b * d.heads + h) * n + i) * 2] = m;
+    ml[(((long)b * d.heads + h) * n + i) * 2 + 1] = l;
+  }
+}
+
+template <int DK4>
+__global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                const float* __restrict__ ml,
+                                                                const unsigned char* __restrict__ keep,
+                                                                unsigned long long seed, float p_drop,
+                                                                float* __restrict__ d_qkv, AttnDims d) {
+  extern __shared__ float lds[];
+  constexpr int DKP = DK4 * 4;
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+  const int mp = n | 1;            // odd pitch: row-wise writes and column-wise reads are both conflict-free
+  float* qs = lds;                 // [n][DKP], already divided by the temperature
+  float* ks = qs + n * DKP;
+  float* vs = ks + n * DKP;
+  float* dos = vs + n * DKP;
+  float* M = dos + n * DKP;        // [n][mp]: first the kept, rescaled weights (for dV), then ds (for dK)
+  const long base = (long)b * n;
+  const float temp = sqrtf((float)dk);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  stage_head<DK4>(qs, qkv, base, O, h * dk, n, dk, temp);
+  stage_head<DK4>(ks, qkv, base, O, d.hd + h * dk, n, dk, 0.f);
+  stage_head<DK4>(vs, qkv, base, O, 2 * d.hd + h * dk, n, dk, 0.f);
+  stage_head<DK4>(dos, d_o, base, d.hd, h * dk, n, dk, 0.f);
+  __syncthreads();
+  const int i = threadIdx.x;
+  const bool act = i < n;
+  const int ic = act ? i : 0;
+  const long mlrow = (((long)b * d.heads + h) * n + ic);
+  const float mi = ml[mlrow * 2], li = 1.f / ml[mlrow * 2 + 1];
+  const long mrow = mlrow * n;
+  float q[DKP], dout[DKP];
+#pragma unroll
+  for (int c4 = 0; c4 < DK4; ++c4) {
+    const float4 a = ld4(qs + ic * DKP + 4 * c4), g = ld4(dos + ic * DKP + 4 * c4);
+    q[4 * c4] = a.x; q[4 * c4 + 1] = a.y; q[4 * c4 + 2] = a.z; q[4 * c4 + 3] = a.w;
+    dout[4 * c4] = g.x; dout[4 * c4 + 1] = g.y; dout[4 * c4 + 2] = g.z; dout[4 * c4 + 3] = g.w;
+  }
+  // ---- phase 1 (lane = query): p_ij, D_i; kept weights to M
+  float pr[AW];
+  unsigned long long kept = 0ull;
+  float Di = 0.f;
+#pragma unroll
+  for (int j = 0; j < AW; ++j) {
+    if (j < n) {
+      const float sj = dot_row<DK4>(q, ks + j * DKP);
+      const bool kp = keep_elem(keep, seed, p_drop, mrow + j);
+      const float dp = kp ? dot_row<DK4>(dout, vs + j * DKP) : 0.f;
+      pr[j] = expf(sj - mi) * li;
+      Di = fmaf(pr[j], dp * inv_keep, Di);
+      kept |= kp ? (1ull << j) : 0ull;
+      if (act) M[i * mp + j] = kp ? pr[j] * inv_keep : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2a (lane = key): dV_j = sum_i pk_ij dO_i
+  float dvv[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) dvv[c] = 0.f;
+  for (int r = 0; r < n; ++r) axpy_row<DK4>(M[r * mp + ic], dos + r * DKP, dvv);
+  __syncthreads();
+  // ---- phase 1b (lane = query): ds_ij, dQ_i; ds to M
+  float dq[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) dq[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < AW; ++j) {
+    if (j < n) {
+      const float dp = ((kept >> j) & 1ull) ? dot_row<DK4>(dout, vs + j * DKP) : 0.f;
+      const float ds = pr[j] * (dp * inv_keep - Di);
+      axpy_row<DK4>(ds, ks + j * DKP, dq);
+      if (act) M[i * mp + j] = ds;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2b (lane = key): dK_j = sum_i ds_ij q_i
+  float dkk[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) dkk[c] = 0.f;
+  for (int r = 0; r < n; ++r) axpy_row<DK4>(M[r * mp + ic], qs + r * DKP, dkk);
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < DKP; ++c)
+      if (c < dk) {
+        d_qkv[(base + i) * O + h * dk + c] = dq[c] / temp;
+        d_qkv[(base + i) * O + d.hd + h * dk + c] = dkk[c];
+        d_qkv[(base + i) * O + 2 * d.hd + h * dk + c] = dvv[c];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // C: o, x1 -> y1 = o Wfc^T + x1 -> xhat1 -> x2 -> hdn = relu(x2 W1^T + b1) -> y2 = hdn W2^T + b2 + x2 -> xhat2 -> x3
 struct PostParams {
   const float *fc, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b, *vad_w, *vad_b;
@@ -728,9 +921,22 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
   if (check_attn("noise_attn_core_fwd", ntok, n, d_model, heads, dk)) return -1;
   NOISE_REQUIRE(qkv && o, "noise_attn_core_fwd: null pointer");
   NOISE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "noise_attn_core_fwd: p_drop=%f out of range", p_drop);
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  if (n <= AW) {   // one wave per (clip, head)
+    const int dk4 = (dk + 3) / 4;
+    const size_t sm = (size_t)2 * n * dk4 * 4 * sizeof(float);
+    const dim3 grid((unsigned)(ntok / n) * heads);
+#define X(K4)                                                                                                     \
+  if (dk4 == K4)                                                                                                  \
+    hipLaunchKernelGGL(attn_core_fwd_wave_kernel<K4>, grid, dim3(AW), sm, (hipStream_t)stream, qkv, o, ml, keep, seed, \
+                       p_drop, d);
+    X(1) X(2) X(3) X(4)
+#undef X
+    NOISE_CHECK_LAUNCH("noise_attn_core_fwd/wave");
+    return 0;
+  }
   const size_t smem = (size_t)2 * n * dk * sizeof(float);
   NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_fwd: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
-  AttnDims d{ntok, n, heads, dk, heads * dk};
   NOISE_ALLOW_LDS(attn_core_fwd_kernel, smem);
   hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)(ntok / n) * heads), dim3(256), smem, (hipStream_t)stream, qkv, o,
                      ml, keep, seed, p_drop, d);
@@ -743,9 +949,22 @@ NOISE_EXPORT int noise_attn_core_bwd(const float* qkv, const float* d_o, const f
                                      int heads, int dk, void* stream) {
   if (check_attn("noise_attn_core_bwd", ntok, n, d_model, heads, dk)) return -1;
   NOISE_REQUIRE(qkv && d_o && ml && d_qkv, "noise_attn_core_bwd: null pointer");
+  AttnDims d{ntok, n, heads, dk, heads * dk};
+  if (n <= AW) {   // one wave per (clip, head)
+    const int dk4 = (dk + 3) / 4;
+    const size_t sm = (size_t)(4 * n * dk4 * 4 + n * (n | 1)) * sizeof(float);
+    const dim3 grid((unsigned)(ntok / n) * heads);
+#define X(K4)                                                                                                        \
+  if (dk4 == K4)                                                                                                     \
+    hipLaunchKernelGGL(attn_core_bwd_wave_kernel<K4>, grid, dim3(AW), sm, (hipStream_t)stream, qkv, d_o, ml, keep, seed, \
+                       p_drop, d_qkv, d);
+    X(1) X(2) X(3) X(4)
+#undef X
+    NOISE_CHECK_LAUNCH("noise_attn_core_bwd/wave");
+    return 0;
+  }
   const size_t smem = (size_t)(4 * n * dk + 3 * n) * sizeof(float);
   NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_bwd: n=%d tokens per clip exceed the LDS limit", n);
-  AttnDims d{ntok, n, heads, dk, heads * dk};
   NOISE_ALLOW_LDS(attn_core_bwd_kernel, smem);
   hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)(ntok / n) * heads), dim3(256), smem, (hipStream_t)stream, qkv,
                      d_o, ml, keep, seed, p_drop, d_qkv, d);
