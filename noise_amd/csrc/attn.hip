@@ -152,12 +152,17 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
 __device__ __forceinline__ bool keep_elem(const unsigned char* keep, unsigned long long seed, float p_drop, long idx) {
   if (keep) return keep[idx] != 0;
   if (p_drop <= 0.f) return true;
-  // counter-based hash (splitmix64 finaliser) -> uniform in [0,1)
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.f / 16777216.f) >= p_drop;
+  // counter-based hash of (seed, element index): two 32-bit multiply-xorshift rounds (murmur3 finaliser) -> uniform
+  // in [0,1).  32-bit arithmetic keeps it to a dozen VALU instructions per attention weight.
+  unsigned x = (unsigned)idx ^ (unsigned)seed;
+  x *= 0x9E3779B1u;
+  x ^= (unsigned)(seed >> 32) + (unsigned)((unsigned long long)idx >> 32) * 0x85EBCA6Bu;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return (float)(x >> 8) * (1.f / 16777216.f) >= p_drop;
 }
 
 constexpr int DKMAX = 16;
