@@ -498,14 +498,23 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
     wd.wown = cell ? Wi : d.Wo;
     walk_plan(wd, cell ? Hi : d.Ho, noise_conv_max_blocks(), grid);
     if (slab_rows) *slab_rows = grid;
+    const bool hb = b_y != nullptr;
+#define LAUNCH_FWD(...)                                                                                            \
+  do {                                                                                                             \
+    if (hb)                                                                                                        \
+      hipLaunchKernelGGL((__VA_ARGS__ true>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);          \
+    else                                                                                                           \
+      hipLaunchKernelGGL((__VA_ARGS__ false>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);         \
+  } while (0)
     if (cell)
-      hipLaunchKernelGGL(walk_cell_fwd_kernel, dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+      LAUNCH_FWD(walk_cell_fwd_kernel<);
     else if (transposed)
-      hipLaunchKernelGGL((walk_gather_fwd_kernel<1, true>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+      LAUNCH_FWD(walk_gather_fwd_kernel<1, true,);
     else if (sy == 1)
-      hipLaunchKernelGGL((walk_gather_fwd_kernel<1, false>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+      LAUNCH_FWD(walk_gather_fwd_kernel<1, false,);
     else
-      hipLaunchKernelGGL((walk_gather_fwd_kernel<2, false>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);
+      LAUNCH_FWD(walk_gather_fwd_kernel<2, false,);
+#undef LAUNCH_FWD
     NOISE_CHECK_LAUNCH("noise_dw3x3_fwd");
     return 0;
   }
@@ -552,14 +561,27 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
     const bool cell = !transposed && sy == 2;
     wd.wown = cell ? d.Wo : Wi;
     walk_plan(wd, cell ? d.Ho : Hi, noise_conv_max_blocks(), grid);
+    const bool hb = b_y != nullptr, hg = g_other != nullptr;
+#define LAUNCH_BWD(...)                                                                                             \
+  do {                                                                                                              \
+    if (hb && hg)                                                                                                   \
+      hipLaunchKernelGGL((__VA_ARGS__ true, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);   \
+    else if (hb)                                                                                                    \
+      hipLaunchKernelGGL((__VA_ARGS__ true, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+    else if (hg)                                                                                                    \
+      hipLaunchKernelGGL((__VA_ARGS__ false, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+    else                                                                                                            \
+      hipLaunchKernelGGL((__VA_ARGS__ false, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
+  } while (0)
     if (cell)
-      hipLaunchKernelGGL(walk_cell_bwd_kernel, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+      LAUNCH_BWD(walk_cell_bwd_kernel<);
     else if (!transposed)
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<1, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+      LAUNCH_BWD(walk_gather_bwd_kernel<1, true,);
     else if (sy == 1)
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<1, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+      LAUNCH_BWD(walk_gather_bwd_kernel<1, false,);
     else
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);
+      LAUNCH_BWD(walk_gather_bwd_kernel<2, false,);
+#undef LAUNCH_BWD
   } else {
     grid = conv_grid((long)B * Hi * Wi, C);
     // the adjoint of a CONV gather is a CONVT gather and vice versa
@@ -641,8 +663,12 @@ NOISE_EXPORT int noise_last_convT_fwd(const float* a_y, const float* a_coef, int
     LastWalkDims wd{B, Hi, Wi, C, H, W, Hfull - H, Wfull - W, 0, 0, 0, 0, 0, 0};
     int grid;
     last_walk_plan(wd, true, 4096, grid);
-    hipLaunchKernelGGL(last_cell_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag, absmax,
-                       enh, filt, wd);
+    if (b_y != nullptr)
+      hipLaunchKernelGGL(last_cell_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
+                         absmax, enh, filt, wd);
+    else
+      hipLaunchKernelGGL(last_cell_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
+                         absmax, enh, filt, wd);
   } else if (CG <= 16 && (CG & (CG - 1)) == 0) {
     const int grid = noise_grid((long)B * H * W, 256 / CG, 8192);
     hipLaunchKernelGGL(last_convT_fwd_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
@@ -676,8 +702,20 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
   if (sy == 2 && sx == 2) {
     LastWalkDims wd{B, Hi, Wi, C, H, W, Hfull - H, Wfull - W, 0, 0, 0, 0, 0, 0};
     last_walk_plan(wd, false, noise_conv_max_blocks(), grid);
-    hipLaunchKernelGGL(last_gather_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
-                       absmax, A, Bs, w, g_in, scratch, E, wd);
+    const size_t sm = (size_t)PPB * 12 * C * sizeof(float);
+    const bool hb = b_y != nullptr, hg = g_other != nullptr;
+    if (hb && hg)
+      hipLaunchKernelGGL((last_gather_bwd_kernel<true, true>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
+                         g_in, scratch, E, wd);
+    else if (hb)
+      hipLaunchKernelGGL((last_gather_bwd_kernel<true, false>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
+                         g_in, scratch, E, wd);
+    else if (hg)
+      hipLaunchKernelGGL((last_gather_bwd_kernel<false, true>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
+                         g_in, scratch, E, wd);
+    else
+      hipLaunchKernelGGL((last_gather_bwd_kernel<false, false>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
+                         g_in, scratch, E, wd);
   } else {
     hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
                        absmax, A, Bs, w, g_in, scratch, E, d);

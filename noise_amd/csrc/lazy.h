@@ -21,15 +21,23 @@ __device__ __forceinline__ float4 relu6_4(float4 v) { return make_float4(relu6f(
 struct Lazy4 {
   const float* y;
   float4 scale, shift;
+  float lo, hi;   // clamp bounds of the activation: (0, 6) for ReLU6, (-inf, +inf) for none, so it needs no branch
   int act;
   bool present;
 };
+
+__device__ __forceinline__ float4 clamp4(float4 v, float lo, float hi) {
+  return make_float4(fminf(fmaxf(v.x, lo), hi), fminf(fmaxf(v.y, lo), hi), fminf(fmaxf(v.z, lo), hi),
+                     fminf(fmaxf(v.w, lo), hi));
+}
 
 __device__ __forceinline__ Lazy4 lazy4_init(const LazySrc& s, int C, int c) {
   Lazy4 r;
   r.y = s.y;
   r.present = s.y != nullptr;
   r.act = s.relu6;
+  r.lo = s.relu6 ? 0.f : -INFINITY;
+  r.hi = s.relu6 ? 6.f : INFINITY;
   r.scale = f4(1.f);
   r.shift = f4(0.f);
   if (r.present && s.coef != nullptr) {
@@ -40,10 +48,12 @@ __device__ __forceinline__ Lazy4 lazy4_init(const LazySrc& s, int C, int c) {
 }
 
 // value of the source at flat element offset `off` (= pixel*C + c)
-__device__ __forceinline__ float4 lazy4_at(const Lazy4& s, size_t off) {
-  float4 v = fma4(ld4(s.y + off), s.scale, s.shift);
-  return s.act == ACT_RELU6 ? relu6_4(v) : v;
+// activation of an already loaded raw value
+__device__ __forceinline__ float4 lazy4_act(const Lazy4& s, float4 raw) {
+  return clamp4(fma4(raw, s.scale, s.shift), s.lo, s.hi);
 }
+
+__device__ __forceinline__ float4 lazy4_at(const Lazy4& s, size_t off) { return lazy4_act(s, ld4(s.y + off)); }
 
 // Per-thread view of a lazy gradient restricted to 4 consecutive channels.
 // coef3 holds six per-channel vectors [s | k1_hi | k1_lo | a2 | mean_hi | mean_lo] and
@@ -61,8 +71,8 @@ struct LazyGrad4 {
 __device__ __forceinline__ LazyGrad4 lazygrad4_init(const LazyGrad& g, int C, int c) {
   LazyGrad4 r;
   r.dz = g.dz;
-  r.y = g.y;
   r.affine = g.coef3 != nullptr;
+  r.y = r.affine ? g.y : g.dz;   // without coefficients the formula below is the identity on dz (s = 1, a2 = 0)
   r.s = f4(1.f);
   r.k1h = r.k1l = r.a2 = r.mh = r.ml = f4(0.f);
   if (r.affine) {
@@ -76,12 +86,15 @@ __device__ __forceinline__ LazyGrad4 lazygrad4_init(const LazyGrad& g, int C, in
   return r;
 }
 
-__device__ __forceinline__ float4 lazygrad4_at(const LazyGrad4& g, size_t off) {
-  const float4 d = ld4(g.dz + off);
-  if (!g.affine) return d;
+// dy from already loaded dz and y (y is ignored when there are no coefficients)
+__device__ __forceinline__ float4 lazygrad4_eval(const LazyGrad4& g, float4 d, float4 y) {
   const float4 t1 = sub4(sub4(d, g.k1h), g.k1l);
-  const float4 t2 = sub4(sub4(ld4(g.y + off), g.mh), g.ml);
+  const float4 t2 = sub4(sub4(y, g.mh), g.ml);
   return fma4(g.a2, t2, g.s * t1);
+}
+
+__device__ __forceinline__ float4 lazygrad4_at(const LazyGrad4& g, size_t off) {
+  return lazygrad4_eval(g, ld4(g.dz + off), ld4(g.y + off));
 }
 
 __device__ __forceinline__ float lazygrad1(float dz, float y, float s, float k1h, float k1l, float a2, float mh, float ml) {
@@ -92,6 +105,7 @@ __device__ __forceinline__ float lazygrad1(float dz, float y, float s, float k1h
 struct Epi4 {
   const float* g_other;
   float4 scale, shift, mean, mlo, istd;
+  float rlo, rhi;   // the gradient passes where rlo < scale*y + shift < rhi: (0, 6) for ReLU6, (-inf, +inf) otherwise
   bool stats, relu6;
 };
 
@@ -100,6 +114,8 @@ __device__ __forceinline__ Epi4 epi4_init(const BwdEpilogue& e, int C, int c) {
   r.g_other = e.g_other;
   r.stats = e.coef != nullptr;
   r.relu6 = e.relu6 != 0;
+  r.rlo = (r.stats && r.relu6) ? 0.f : -INFINITY;
+  r.rhi = (r.stats && r.relu6) ? 6.f : INFINITY;
   r.scale = f4(1.f);
   r.shift = r.mean = r.mlo = f4(0.f);
   r.istd = f4(1.f);
@@ -115,6 +131,21 @@ __device__ __forceinline__ Epi4 epi4_init(const BwdEpilogue& e, int C, int c) {
 
 // Applies the epilogue to gradient g of the element whose raw producer output is yraw; accumulates the
 // two BatchNorm-backward sums.  Returns the value to store.
+// Core of the epilogue on a gradient that already includes g_other.
+// Branch-free: without producer coefficients the mask bounds are infinite and the two sums are accumulated from
+// identity coefficients (nobody reads them); yraw must be a finite, really loaded value.
+__device__ __forceinline__ float4 epi4_core(const Epi4& e, float4 g, float4 yraw, float4& s1, float4& s2) {
+  const float4 v = fma4(yraw, e.scale, e.shift);
+  g.x = (v.x > e.rlo && v.x < e.rhi) ? g.x : 0.f;
+  g.y = (v.y > e.rlo && v.y < e.rhi) ? g.y : 0.f;
+  g.z = (v.z > e.rlo && v.z < e.rhi) ? g.z : 0.f;
+  g.w = (v.w > e.rlo && v.w < e.rhi) ? g.w : 0.f;
+  const float4 xh = sub4(sub4(yraw, e.mean), e.mlo) * e.istd;
+  s1 = s1 + g;
+  s2 = fma4(g, xh, s2);
+  return g;
+}
+
 // `ok` = false marks a pixel that does not exist (its g must already be zero): nothing is accumulated for it.
 __device__ __forceinline__ float4 epi4_apply(const Epi4& e, float4 g, float4 yraw, size_t off, float4& s1, float4& s2,
                                              bool ok = true) {

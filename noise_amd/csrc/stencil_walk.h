@@ -56,7 +56,9 @@ __device__ __forceinline__ bool walk_slot(const WalkDims& d, int slot, int nrows
 
 // ------------------------------------------------------------------------------------------------
 // forward, gather geometry
-template <int S, bool FLIP>
+// HAS_B (here and below): the input is the sum of two lazy sources.  Optional operands are template flags, not
+// run-time tests: a branch around a load makes the compiler wait for ALL outstanding loads behind it.
+template <int S, bool FLIP, bool HAS_B>
 __global__ __launch_bounds__(256) void walk_gather_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
                                                               float* __restrict__ out, float* __restrict__ slab,
                                                               WalkDims d) {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void walk_gather_fwd_kernel(LazySrc A, LazySrc
         const size_t row = clip + (size_t)(vy ? iy : 0) * d.Ws * C;
         const size_t o0 = row + (size_t)cx0 * C, o1 = row + (size_t)cx1 * C, o2 = row + (size_t)cx2 * C;
         float4 x0 = lazy4_at(a, o0), x1 = lazy4_at(a, o1), x2 = lazy4_at(a, o2);
-        if (b.present) {
+        if (HAS_B) {
           x0 = x0 + lazy4_at(b, o0);
           x1 = x1 + lazy4_at(b, o1);
           x2 = x2 + lazy4_at(b, o2);
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void walk_gather_fwd_kernel(LazySrc A, LazySrc
 }
 
 // forward, cell geometry (transposed convolution, stride 2)
+template <bool HAS_B>
 __global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
                                                             float* __restrict__ out, float* __restrict__ slab,
                                                             WalkDims d) {
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc B
         const bool vy = iy < d.Hs;
         const size_t o0 = clip + ((size_t)(vy ? iy : 0) * d.Ws + mx) * C, o1 = vx1 ? o0 + C : o0;
         float4 x0 = lazy4_at(a, o0), x1 = lazy4_at(a, o1);
-        if (b.present) {
+        if (HAS_B) {
           x0 = x0 + lazy4_at(b, o0);
           x1 = x1 + lazy4_at(b, o1);
         }
@@ -214,15 +217,15 @@ struct BwdPixel {
 
 // Finishes one destination pixel: weight-gradient contribution is done by the caller (it needs av), this applies
 // the epilogue and stores.
+template <bool HAS_B>
 __device__ __forceinline__ float4 bwd_activation(const BwdPixel& p, size_t off, float4& yraw) {
   yraw = ld4(p.a.y + off);
-  float4 av = fma4(yraw, p.a.scale, p.a.shift);
-  if (p.a.act == ACT_RELU6) av = relu6_4(av);
-  if (p.b.present) av = av + lazy4_at(p.b, off);
+  float4 av = lazy4_act(p.a, yraw);
+  if (HAS_B) av = av + lazy4_at(p.b, off);
   return av;
 }
 
-template <int S, bool FLIP>
+template <int S, bool FLIP, bool HAS_B, bool HAS_GO>
 __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
                                                               const float* __restrict__ w, float* __restrict__ g_in,
                                                               float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
@@ -258,16 +261,57 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
       load_row(r0 * S - 1, t0);
       if (S == 1) load_row(r0, t1);
       size_t ioff = (((size_t)bi * d.Hd + r0) * d.Wd + ox) * C + c;
-#pragma unroll 1
-      for (int oy = r0; oy < r1; ++oy, ioff += (size_t)d.Wd * C) {
-        if (S == 1) {
-          load_row(oy + 1, t2);
-        } else {
-          load_row(2 * oy, t1);
-          load_row(2 * oy + 1, t2);
+      const size_t drow = (size_t)d.Wd * C;
+      // Software pipeline: everything the NEXT step needs from memory (S source rows of dz / y, the destination
+      // pixel's activation and second gradient) is requested before the arithmetic of the current step, so a
+      // thread always has one step of loads in flight.
+      float4 rz[S][3], ry[S][3], ray, rby, rgo;
+      auto issue = [&](int oy, size_t off) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+          const int iy = S == 1 ? oy + 1 : 2 * oy + u;
+          const size_t row = clip + (size_t)((iy >= 0 && iy < d.Hs) ? iy : 0) * d.Ws * C;
+          rz[u][0] = ld4(gr.dz + row + (size_t)cx0 * C);
+          rz[u][1] = ld4(gr.dz + row + (size_t)cx1 * C);
+          rz[u][2] = ld4(gr.dz + row + (size_t)cx2 * C);
+          ry[u][0] = ld4(gr.y + row + (size_t)cx0 * C);
+          ry[u][1] = ld4(gr.y + row + (size_t)cx1 * C);
+          ry[u][2] = ld4(gr.y + row + (size_t)cx2 * C);
         }
-        float4 yraw;
-        const float4 av = bwd_activation(px, ioff, yraw);
+        ray = ld4(px.a.y + off);
+        rby = HAS_B ? ld4(px.b.y + off) : f4(0.f);
+        rgo = HAS_GO ? ld4(px.epi.g_other + off) : f4(0.f);
+      };
+      issue(r0, ioff);
+#pragma unroll 1
+      for (int oy = r0; oy < r1; ++oy, ioff += drow) {
+        if (S == 1) {
+          const bool vy = oy + 1 < d.Hs;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) t2[j] = lazygrad4_eval(gr, rz[0][j], ry[0][j]);
+          t2[0] = keep4(vy && v0, t2[0]);
+          t2[1] = keep4(vy && v1, t2[1]);
+          t2[2] = keep4(vy && v2, t2[2]);
+        } else {
+          const bool vy2 = 2 * oy + 1 < d.Hs;   // row 2*oy always exists
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            t1[j] = lazygrad4_eval(gr, rz[0][j], ry[0][j]);
+            t2[j] = lazygrad4_eval(gr, rz[S - 1][j], ry[S - 1][j]);
+          }
+          t1[0] = keep4(v0, t1[0]);
+          t1[1] = keep4(v1, t1[1]);
+          t1[2] = keep4(v2, t1[2]);
+          t2[0] = keep4(vy2 && v0, t2[0]);
+          t2[1] = keep4(vy2 && v1, t2[1]);
+          t2[2] = keep4(vy2 && v2, t2[2]);
+        }
+        const float4 yraw = ray;
+        float4 av = lazy4_act(px.a, yraw);
+        if (HAS_B) av = av + lazy4_act(px.b, rby);
+        const float4 go = rgo;
+        issue(oy + 1 < r1 ? oy + 1 : oy, oy + 1 < r1 ? ioff + drow : ioff);   // next step (a harmless repeat at the end)
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic below
         float4 acc = t0[0] * wk[0];
         acc = fma4(t0[1], wk[1], acc);
         acc = fma4(t0[2], wk[2], acc);
@@ -283,7 +327,7 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
           dwk[3 + j] = fma4(t1[j], av, dwk[3 + j]);
           dwk[6 + j] = fma4(t2[j], av, dwk[6 + j]);
         }
-        acc = epi4_apply(px.epi, acc, yraw, ioff, dwk[9], dwk[10]);
+        acc = epi4_core(px.epi, acc + go, yraw, dwk[9], dwk[10]);
         if (g_in != nullptr) st4(g_in + ioff, acc);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -309,6 +353,7 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
 }
 
 // backward of a stride-2 Conv2d: cell geometry over dy
+template <bool HAS_B, bool HAS_GO>
 __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
                                                             const float* __restrict__ w, float* __restrict__ g_in,
                                                             float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
@@ -340,17 +385,46 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
       load_row(m0, s00, s01);
       size_t ioff = (((size_t)bi * d.Hd + 2 * m0) * d.Wd + 2 * mx) * C + c;
       const size_t drow = (size_t)d.Wd * C;
+      // Software pipeline (see walk_gather_bwd_kernel): the source row and the four raw destination activations of the
+      // NEXT cell are requested before the arithmetic of the current one.  A destination pixel outside the tensor is
+      // redirected to (2m, 2mx): its loads are harmless and its results are neither accumulated nor stored.
+      float4 rz0, rz1, ry0, ry1, ra[4];
+      auto issue = [&](int m, size_t off) {
+        const int iy = m + 1;
+        const size_t o0 = clip + ((size_t)(iy < d.Hs ? iy : 0) * d.Ws + mx) * C, o1 = vx1 ? o0 + C : o0;
+        rz0 = ld4(gr.dz + o0);
+        rz1 = ld4(gr.dz + o1);
+        ry0 = ld4(gr.y + o0);
+        ry1 = ld4(gr.y + o1);
+        const bool k10 = 2 * m + 1 < d.Hd;
+        ra[0] = ld4(px.a.y + off);
+        ra[1] = ld4(px.a.y + (dx1 ? off + C : off));
+        ra[2] = ld4(px.a.y + (k10 ? off + drow : off));
+        ra[3] = ld4(px.a.y + ((k10 && dx1) ? off + drow + C : off));
+      };
+      auto activate = [&](float4 yraw, size_t off) {
+        float4 av = lazy4_act(px.a, yraw);
+        if (HAS_B) av = av + lazy4_at(px.b, off);
+        return av;
+      };
+      auto finish = [&](float4 g, float4 yraw, size_t off, bool ok) {   // + second gradient, mask, producer sums
+        if (HAS_GO) g = g + keep4(ok, ld4(px.epi.g_other + off));
+        return epi4_core(px.epi, g, yraw, dwk[9], dwk[10]);
+      };
+      issue(m0, ioff);
 #pragma unroll 1
       for (int m = m0; m < m1; ++m, ioff += 2 * drow) {
-        load_row(m + 1, s10, s11);
-        // the four destination pixels of this cell; a pixel outside the tensor is redirected to (2m, 2mx), its
-        // loads are harmless and its results are neither accumulated nor stored
+        const bool vy = m + 1 < d.Hs;
+        s10 = keep4(vy, lazygrad4_eval(gr, rz0, ry0));
+        s11 = keep4(vy && vx1, lazygrad4_eval(gr, rz1, ry1));
         const bool ok01 = dx1, ok10 = 2 * m + 1 < d.Hd, ok11 = ok10 && dx1;
         const size_t o00 = ioff, o01 = ok01 ? ioff + C : ioff, o10 = ok10 ? ioff + drow : ioff,
                      o11 = ok11 ? ioff + drow + C : ioff;
-        float4 y00, y01, y10, y11;
-        const float4 a00 = bwd_activation(px, o00, y00), a01 = keep4(ok01, bwd_activation(px, o01, y01));
-        const float4 a10 = keep4(ok10, bwd_activation(px, o10, y10)), a11 = keep4(ok11, bwd_activation(px, o11, y11));
+        const float4 y00 = ra[0], y01 = ra[1], y10 = ra[2], y11 = ra[3];
+        issue(m + 1 < m1 ? m + 1 : m, m + 1 < m1 ? ioff + 2 * drow : ioff);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic below
+        const float4 a00 = activate(y00, o00), a01 = keep4(ok01, activate(y01, o01));
+        const float4 a10 = keep4(ok10, activate(y10, o10)), a11 = keep4(ok11, activate(y11, o11));
         float4 g00 = s00 * wk[4];
         float4 g01 = fma4(s01, wk[3], s00 * wk[5]);
         float4 g10 = fma4(s10, wk[1], s00 * wk[7]);
@@ -367,10 +441,10 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
         dwk[6] = fma4(s01, a11, dwk[6]);
         dwk[2] = fma4(s10, a11, dwk[2]);
         dwk[0] = fma4(s11, a11, dwk[0]);
-        g00 = epi4_apply(px.epi, g00, y00, o00, dwk[9], dwk[10]);
-        g01 = epi4_apply(px.epi, keep4(ok01, g01), y01, o01, dwk[9], dwk[10], ok01);
-        g10 = epi4_apply(px.epi, keep4(ok10, g10), y10, o10, dwk[9], dwk[10], ok10);
-        g11 = epi4_apply(px.epi, keep4(ok11, g11), y11, o11, dwk[9], dwk[10], ok11);
+        g00 = finish(g00, y00, o00, true);
+        g01 = finish(keep4(ok01, g01), y01, o01, ok01);
+        g10 = finish(keep4(ok10, g10), y10, o10, ok10);
+        g11 = finish(keep4(ok11, g11), y11, o11, ok11);
         if (g_in != nullptr) {
           st4(g_in + o00, g00);
           if (ok01) st4(g_in + o01, g01);
@@ -414,6 +488,7 @@ struct LastWalkDims {
 };
 
 // forward: filt(Y, X) = bias + sum_c sum_k a[(Y+1-ky)/2][(X+1-kx)/2][c] * w[c][k];  enh = clamp(x/max + filt)*max
+template <bool HAS_B>
 __global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ logmag,
@@ -442,7 +517,7 @@ __global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc B
       const bool vy = iy < d.Hi;
       const size_t o0 = clip + ((size_t)(vy ? iy : 0) * d.Wi + mx) * C, o1 = vx1 ? o0 + C : o0;
       float4 x0 = lazy4_at(a, o0), x1 = lazy4_at(a, o1);
-      if (b.present) {
+      if (HAS_B) {
         x0 = x0 + lazy4_at(b, o0);
         x1 = x1 + lazy4_at(b, o1);
       }
@@ -489,6 +564,7 @@ __global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc B
 // backward: dy0(Y, X) = d_enh * max * [|enh| < max] inside the crop, 0 outside;
 //   g_in[i][c] = sum_k dy0(2i - 1 + k) * w[c][k];   dW[c][k] += a[i][c] * dy0(2i - 1 + k);   db = sum dy0
 // Slab rows are 12*C floats: 9 taps | bias gradient at column 9*C | producer BatchNorm sums at [10C, 12C).
+template <bool HAS_B, bool HAS_GO>
 __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __restrict__ d_enh, const float* __restrict__ enh,
                                                               const float* __restrict__ absmax, LazySrc A, LazySrc Bsrc,
                                                               const float* __restrict__ w, float* __restrict__ g_in,
@@ -532,7 +608,8 @@ __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __res
         load_row(2 * iy - d.oy0, t1);
         load_row(2 * iy + 1 - d.oy0, t2);
         float4 yraw;
-        const float4 av = bwd_activation(px, ioff, yraw);
+        const float4 av = bwd_activation<HAS_B>(px, ioff, yraw);
+        const float4 go = HAS_GO ? ld4(px.epi.g_other + ioff) : f4(0.f);
         float4 acc = f4(t0[0]) * wk[0];
         acc = fma4(f4(t0[1]), wk[1], acc);
         acc = fma4(f4(t0[2]), wk[2], acc);
@@ -550,7 +627,7 @@ __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __res
         }
         // every output (Y, X) is tap (1|2, 1|2) of exactly one input pixel: those four carry the bias gradient
         db += (t1[1] + t1[2]) + (t2[1] + t2[2]);
-        acc = epi4_apply(px.epi, acc, yraw, ioff, dwk[10], dwk[11]);
+        acc = epi4_core(px.epi, acc + go, yraw, dwk[10], dwk[11]);
         st4(g_in + ioff, acc);
 #pragma unroll
         for (int j = 0; j < 3; ++j) t0[j] = t2[j];
