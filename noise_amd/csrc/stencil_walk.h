@@ -604,12 +604,43 @@ __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __res
       float t0[3], t1[3], t2[3];
       load_row(2 * r0 - 1 - d.oy0, t0);
       size_t ioff = (((size_t)bi * d.Hi + r0) * d.Wi + ix) * C + c;
-      for (int iy = r0; iy < r1; ++iy, ioff += (size_t)d.Wi * C) {
-        load_row(2 * iy - d.oy0, t1);
-        load_row(2 * iy + 1 - d.oy0, t2);
-        float4 yraw;
-        const float4 av = bwd_activation<HAS_B>(px, ioff, yraw);
-        const float4 go = HAS_GO ? ld4(px.epi.g_other + ioff) : f4(0.f);
+      const size_t drow = (size_t)d.Wi * C;
+      // software pipeline (see walk_gather_bwd_kernel): the next input row's operands are requested first
+      float re[2][3], rg[2][3];
+      float4 ray, rby, rgo;
+      auto issue = [&](int iy, size_t off) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int Y = 2 * iy + u - d.oy0;
+          const size_t row = oclip + (size_t)((Y >= 0 && Y < d.H) ? Y : 0) * d.W;
+          re[u][0] = enh[row + c0];
+          re[u][1] = enh[row + c1];
+          re[u][2] = enh[row + c2];
+          rg[u][0] = d_enh[row + c0];
+          rg[u][1] = d_enh[row + c1];
+          rg[u][2] = d_enh[row + c2];
+        }
+        ray = ld4(px.a.y + off);
+        rby = HAS_B ? ld4(px.b.y + off) : f4(0.f);
+        rgo = HAS_GO ? ld4(px.epi.g_other + off) : f4(0.f);
+      };
+      issue(r0, ioff);
+#pragma unroll 1
+      for (int iy = r0; iy < r1; ++iy, ioff += drow) {
+        const int Y1 = 2 * iy - d.oy0, Y2 = Y1 + 1;
+        const bool vy1 = Y1 >= 0 && Y1 < d.H, vy2 = Y2 >= 0 && Y2 < d.H;
+        t1[0] = (vy1 && v0 && re[0][0] > -mxv && re[0][0] < mxv) ? rg[0][0] * mxv : 0.f;
+        t1[1] = (vy1 && v1 && re[0][1] > -mxv && re[0][1] < mxv) ? rg[0][1] * mxv : 0.f;
+        t1[2] = (vy1 && v2 && re[0][2] > -mxv && re[0][2] < mxv) ? rg[0][2] * mxv : 0.f;
+        t2[0] = (vy2 && v0 && re[1][0] > -mxv && re[1][0] < mxv) ? rg[1][0] * mxv : 0.f;
+        t2[1] = (vy2 && v1 && re[1][1] > -mxv && re[1][1] < mxv) ? rg[1][1] * mxv : 0.f;
+        t2[2] = (vy2 && v2 && re[1][2] > -mxv && re[1][2] < mxv) ? rg[1][2] * mxv : 0.f;
+        const float4 yraw = ray;
+        float4 av = lazy4_act(px.a, yraw);
+        if (HAS_B) av = av + lazy4_act(px.b, rby);
+        const float4 go = rgo;
+        issue(iy + 1 < r1 ? iy + 1 : iy, iy + 1 < r1 ? ioff + drow : ioff);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic below
         float4 acc = f4(t0[0]) * wk[0];
         acc = fma4(f4(t0[1]), wk[1], acc);
         acc = fma4(f4(t0[2]), wk[2], acc);
