@@ -14,6 +14,10 @@
 
 namespace {
 
+// 16 zero bytes that an absent second source points at: its loads stay unconditional (a branch around a load makes
+// the compiler drain every outstanding load behind it) and cost one broadcast cache hit.
+__device__ float4 g_zero4;
+
 struct PwDims {
   long npix;
   int K, N, transW;  // N: output channels = output row stride (multiple of 4)
@@ -58,36 +62,53 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, Laz
 #pragma unroll
   for (int m = 0; m < MT; ++m) s1[m] = s2[m] = f4(0.f);
 
+  // Branch-free operand fetch: clamped (always valid) addresses, an absent second source reads the zero dummy with
+  // element stride 0 and scale 0, an absent activation clamps to (-inf, +inf).  The raw operands of the NEXT tile
+  // are requested before the MFMAs of the current one.
+  const float* zero = reinterpret_cast<const float*>(&g_zero4);
+  const float* src0 = GRAD ? G.dz : A.y;
+  const float* src1 = GRAD ? (G.coef3 ? G.y : G.dz) : (Bs.y ? Bs.y : zero);
+  const size_t mul1 = (GRAD || Bs.y) ? 1 : 0;
+  const bool has_b = !GRAD && Bs.y != nullptr;
+  const float alo = (!GRAD && A.relu6) ? 0.f : -INFINITY, ahi = (!GRAD && A.relu6) ? 6.f : INFINITY;
+  const float blo = (has_b && Bs.relu6) ? 0.f : -INFINITY, bhi = (has_b && Bs.relu6) ? 6.f : INFINITY;
+  const float bgate = has_b ? 1.f : 0.f;
   const long ntiles = (d.npix + 15) >> 4;
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+  float4 r0[KC], r1[KC];
+  auto issue = [&](long tile) {
+    long pix = tile * 16 + p;
+    pix = pix < d.npix ? pix : d.npix - 1;
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) {
+      const int ci = 16 * jj + 4 * q;
+      const size_t off = (size_t)pix * K + (ci < K ? ci : 0);
+      r0[jj] = ld4(src0 + off);
+      r1[jj] = ld4(src1 + off * mul1);
+    }
+  };
+  const long tile0 = (long)blockIdx.x * 4 + wave, tstep = (long)gridDim.x * 4;
+  if (tile0 < ntiles) issue(tile0);
+  for (long tile = tile0; tile < ntiles; tile += tstep) {
     const long pix = tile * 16 + p;
     const bool valid = pix < d.npix;
     float4 in[KC];
 #pragma unroll
     for (int jj = 0; jj < KC; ++jj) {
       const int ci = 16 * jj + 4 * q;
-      float4 v = f4(0.f);
-      if (valid && ci < K) {
-        const size_t off = (size_t)pix * K + ci;
-        if (GRAD) {
-          v = ld4(G.dz + off);
-          if (G.coef3) {
-            const float4 t1 = sub4(sub4(v, ld4(cf + KP + ci)), ld4(cf + 2 * KP + ci));
-            const float4 t2 = sub4(sub4(ld4(G.y + off), ld4(cf + 4 * KP + ci)), ld4(cf + 5 * KP + ci));
-            v = fma4(ld4(cf + 3 * KP + ci), t2, ld4(cf + ci) * t1);
-          }
-        } else {
-          v = fma4(ld4(A.y + off), ld4(cf + ci), ld4(cf + KP + ci));
-          if (A.relu6) v = relu6_4(v);
-          if (Bs.y) {
-            float4 u = fma4(ld4(Bs.y + off), ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci));
-            if (Bs.relu6) u = relu6_4(u);
-            v = v + u;
-          }
-        }
+      float4 v;
+      if (GRAD) {
+        const float4 t1 = sub4(sub4(r0[jj], ld4(cf + KP + ci)), ld4(cf + 2 * KP + ci));
+        const float4 t2 = sub4(sub4(r1[jj], ld4(cf + 4 * KP + ci)), ld4(cf + 5 * KP + ci));
+        v = fma4(ld4(cf + 3 * KP + ci), t2, ld4(cf + ci) * t1);
+      } else {
+        v = clamp4(fma4(r0[jj], ld4(cf + ci), ld4(cf + KP + ci)), alo, ahi);
+        const float4 u = clamp4(fma4(r1[jj], ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci)), blo, bhi);
+        v = fma4(u, f4(bgate), v);
       }
-      in[jj] = v;
+      const bool okc = valid && ci < K;
+      in[jj] = make_float4(okc ? v.x : 0.f, okc ? v.y : 0.f, okc ? v.z : 0.f, okc ? v.w : 0.f);
     }
+    issue(tile + tstep < ntiles ? tile + tstep : tile);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
