@@ -273,7 +273,7 @@ constexpr int pw_bwd_lds_floats(int KC, int MTI) {
 }
 constexpr int pw_bwd_min_blocks(int KC, int MTI) {
   const int b = 160 * 1024 / (pw_bwd_lds_floats(KC, MTI) * 4);
-  const int cap = KC * MTI <= 3 ? 4 : 3;   // 128 registers only fit the smallest tiles without spilling
+  const int cap = KC * MTI <= 3 ? 4 : (MTI >= 4 ? 2 : 3);   // register budget: 128 / 256 / 168 per lane
   return b > cap ? cap : (b < 1 ? 1 : b);
 }
 
@@ -349,6 +349,9 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     bsh = ld4(Bs.coef + K + ck);
   }
 
+  // an absent second gradient reads the zero dummy with element stride 0: its loads need no branch
+  const float* gop = E.g_other ? E.g_other : reinterpret_cast<const float*>(&g_zero4);
+  const size_t gmul = E.g_other ? 1 : 0;
   const long ntiles = (npix + WG_TILE - 1) / WG_TILE;
   const long iters = (ntiles + gridDim.x - 1) / gridDim.x;
   for (long it = 0; it < iters; ++it) {
@@ -423,14 +426,14 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
       const size_t prow = (size_t)(pix < npix ? pix : npix - 1) * K;
       // what the epilogue needs from memory is requested before the MFMA chains (clamped, always valid addresses)
       // when the registers allow it (few input-channel tiles), otherwise tile by tile
-      constexpr bool PRE = MTI <= 3;
+      constexpr bool PRE = MTI <= 6;
       float4 yr[PRE ? MTI : 1], go[PRE ? MTI : 1];
       if (PRE) {
 #pragma unroll
         for (int m = 0; m < MTI; ++m) {
           const int ci = 16 * m + 4 * q, cic = ci < K ? ci : 0;
-          yr[m] = E.coef ? ld4(A.y + prow + cic) : f4(0.f);
-          go[m] = E.g_other ? ld4(E.g_other + prow + cic) : f4(0.f);
+          yr[m] = ld4(A.y + prow + cic);
+          go[m] = ld4(gop + (prow + cic) * gmul);
         }
       }
       float4 in[KC];
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
         if (valid && ci < K) {
           const size_t off = prow + ci;
           float4 g = make_float4(o[0], o[1], o[2], o[3]);
-          if (E.g_other) g = g + (PRE ? go[m] : ld4(E.g_other + off));
+          if (PRE) g = g + go[m];
+          else if (E.g_other) g = g + ld4(E.g_other + off);
           if (E.coef) {
             const float4 yraw = PRE ? yr[m] : ld4(A.y + off);
             if (E.relu6) {
