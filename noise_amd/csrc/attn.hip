@@ -14,6 +14,7 @@ namespace {
 constexpr int D = 64;     // d_model
 constexpr int TT = 64;    // tokens per tile
 constexpr int XS = D + 4; // LDS row pitch of a token tile
+constexpr int WP = D + 4; // LDS row pitch of a weight matrix: the 4 lanes of a token read 4 consecutive rows at once
 
 struct AttnDims {
   long ntok;    // B * n
@@ -58,7 +59,7 @@ __device__ __forceinline__ void row_linear(const float* xrow, const float* Wl, i
   }
   for (int o = part; o < O; o += 4) {
     float acc = bias ? bias[o] : 0.f;
-    const float* wr = Wl + o * K;
+    const float* wr = Wl + o * WP;
 #pragma unroll
     for (int k = 0; k < K; k += 4) {
       const float4 w = ld4(wr + k);
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
                                                            float* __restrict__ qkv, AttnDims d) {
   extern __shared__ float lds[];
   const int O = 3 * d.hd;
-  float* Wl = lds;                  // [O][D]
-  float* xs = Wl + O * D;           // [TT][XS]
+  float* Wl = lds;                  // [O][WP]
+  float* xs = Wl + O * WP;          // [TT][XS]
   float* os = xs + TT * XS;         // [TT][O]
   float* lw = os + TT * O;          // [2][D]
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
     const int o = i / D, k = i - o * D;
     const int which = o / d.hd, oo = o - which * d.hd;
     const float* w = which == 0 ? wq : (which == 1 ? wk : wv);
-    Wl[i] = w[oo * D + k];
+    Wl[o * WP + k] = w[oo * D + k];
   }
   for (int i = tid; i < D; i += 256) {
     lw[i] = ln_w[i];
@@ -526,17 +527,18 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
   extern __shared__ float lds[];
   const int HD = d.hd;
   float* Wfc = lds;                 // [D][HD]
-  float* W1 = Wfc + D * D;          // [D][D]
-  float* W2 = W1 + D * D;           // [D][D]
-  float* vec = W2 + D * D;          // ln0_w, ln0_b, ln1_w, ln1_b, b1, b2, ln2_w, ln2_b, vad_w  (9*D)
+  float* W1 = Wfc + D * D;          // [D][WP]
+  float* W2 = W1 + D * WP;          // [D][WP]
+  float* vec = W2 + D * WP;         // ln0_w, ln0_b, ln1_w, ln1_b, b1, b2, ln2_w, ln2_b, vad_w  (9*D)
   float* ta = vec + 9 * D;          // [TT][XS]
   float* tb = ta + TT * XS;         // [TT][XS]
   float* tc = tb + TT * XS;         // [TT][XS]
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
   for (int i = tid; i < D * HD; i += 256) Wfc[i] = P.fc[i];
   for (int i = tid; i < D * D; i += 256) {
-    W1[i] = P.w1[i];
-    W2[i] = P.w2[i];
+    const int oo = i / D, k = i - oo * D;
+    W1[oo * WP + k] = P.w1[i];
+    W2[oo * WP + k] = P.w2[i];
   }
   for (int i = tid; i < D; i += 256) {
     vec[i] = ln0_w[i]; vec[D + i] = ln0_b[i]; vec[2 * D + i] = P.ln1_w[i]; vec[3 * D + i] = P.ln1_b[i];
@@ -673,10 +675,10 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
                                                             float* __restrict__ slab, AttnDims d) {
   extern __shared__ float lds[];
   const int HD = d.hd;
-  float* WfcT = lds;                // [HD][D]  (transposed: d_o = dy1 Wfc)
-  float* W1T = WfcT + D * D;        // [D][D]   W1T[k][o] = W1[o][k]
-  float* W2T = W1T + D * D;
-  float* vec = W2T + D * D;         // ln1_w, ln2_w, vad_w, ln1_b  (4*D)
+  float* WfcT = lds;                // [HD][WP]  (transposed: d_o = dy1 Wfc)
+  float* W1T = WfcT + D * WP;       // [D][WP]   W1T[k][o] = W1[o][k]
+  float* W2T = W1T + D * WP;
+  float* vec = W2T + D * WP;        // ln1_w, ln2_w, vad_w, ln1_b  (4*D)
   float* ta = vec + 4 * D;
   float* tb = ta + TT * XS;
   float* tc = tb + TT * XS;
@@ -684,12 +686,12 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
   for (int i = tid; i < D * HD; i += 256) {
     const int oo = i / HD, k = i - oo * HD;
-    WfcT[k * D + oo] = P.fc[i];
+    WfcT[k * WP + oo] = P.fc[i];
   }
   for (int i = tid; i < D * D; i += 256) {
     const int oo = i / D, k = i - oo * D;
-    W1T[k * D + oo] = P.w1[i];
-    W2T[k * D + oo] = P.w2[i];
+    W1T[k * WP + oo] = P.w1[i];
+    W2T[k * WP + oo] = P.w2[i];
   }
   for (int i = tid; i < D; i += 256) {
     vec[i] = P.ln1_w[i]; vec[D + i] = P.ln2_w[i]; vec[2 * D + i] = P.vad_w[i]; vec[3 * D + i] = P.ln1_b[i];
@@ -909,7 +911,7 @@ NOISE_EXPORT int noise_attn_pre_fwd(const float* x_y, const float* x_coef, int x
   NOISE_REQUIRE(x_y && ln_w && ln_b && wq && wk && wv && xhat0 && rstd0 && qkv, "noise_attn_pre_fwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   const int O = 3 * d.hd;
-  const size_t smem = (size_t)(O * D + TT * XS + TT * O + 2 * D) * sizeof(float);
+  const size_t smem = (size_t)(O * WP + TT * XS + TT * O + 2 * D) * sizeof(float);
   LazySrc X{x_y, x_coef, x_relu6};
   NOISE_ALLOW_LDS(attn_pre_fwd_kernel, smem);
   hipLaunchKernelGGL(attn_pre_fwd_kernel, dim3(noise_grid(ntok, TT, 1024)), dim3(256), smem, (hipStream_t)stream, X, ln_w,
@@ -989,7 +991,7 @@ NOISE_EXPORT int noise_attn_post_fwd(const float* o, const float* xhat0, const f
                 "noise_attn_post_fwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   PostParams P{fc, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, vad_w, vad_b};
-  const size_t smem = (size_t)(3 * D * D + 9 * D + 3 * TT * XS) * sizeof(float);
+  const size_t smem = (size_t)(D * D + 2 * D * WP + 9 * D + 3 * TT * XS) * sizeof(float);
   NOISE_ALLOW_LDS(attn_post_fwd_kernel, smem);
   hipLaunchKernelGGL(attn_post_fwd_kernel, dim3(noise_grid(ntok, TT, 1024)), dim3(256), smem, (hipStream_t)stream, o, xhat0,
                      ln0_w, ln0_b, P, xhat1, rstd1, hdn, xhat2, rstd2, x3, vad, d);
@@ -1013,7 +1015,7 @@ NOISE_EXPORT int noise_attn_post_bwd(const float* g3, const float* d_vad, const 
   PostParams P{fc, ln1_w, ln1_b, w1, nullptr, w2, nullptr, ln2_w, nullptr, vad_w, nullptr};
   const int ncols = 2 * D * D + D * d.hd + 7 * D + 1;
   const int grid = noise_grid(ntok, TT, ATTN_MAX_BLOCKS);
-  const size_t smem = (size_t)(3 * D * D + 4 * D + 4 * TT * XS) * sizeof(float);
+  const size_t smem = (size_t)(3 * D * WP + 4 * D + 4 * TT * XS) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   NOISE_ALLOW_LDS(attn_post_bwd_kernel, smem);
   hipLaunchKernelGGL(attn_post_bwd_kernel, dim3(grid), dim3(256), smem, st, g3, d_vad, o, xhat1, rstd1, hdn, xhat2, rstd2, x3,
