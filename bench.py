@@ -72,6 +72,25 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"{steps} training steps of {B} x 0.5 s segments (fwd+bwd+AdamW, fp32) on the CPU oracle"}
 
 
+# entry point -> the kernel that moves its bytes (names as rocprofv3 reports them, template arguments dropped)
+MAIN_KERNEL = {"noise_pw_bwd": "pw_bwd_kernel", "noise_pw_fwd": "pw_gemm_kernel", "noise_dw3x3_bwd": "walk_gather_bwd_kernel",
+               "noise_dw3x3_fwd": "walk_gather_fwd_kernel", "noise_last_convT_bwd": "last_gather_bwd_kernel",
+               "noise_last_convT_fwd": "last_cell_fwd_kernel", "noise_stft_fwd": "stft_frames_kernel"}
+
+
+def pmc_traffic(entry_point):
+    """HBM bytes per launch of the entry point's main kernel, from the committed PMC passes of this same command
+    (profiles/r1_hbm_traffic_per_kernel.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
+    FETCH_SIZE doubled as gfx950 requires); None when no such profile is available."""
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_per_kernel.json")
+    kernel = MAIN_KERNEL.get(entry_point)
+    if kernel is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f).get(kernel)
+    return int(rec["hbm_bytes_per_dispatch"]) if rec else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +161,8 @@ def main():
     dom, (dms, dbytes, dn) = rows[0]
     achieved = dbytes / 1e6 / dms  # bytes / ms -> GB/s
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
+                "algorithmic_bytes_per_launch": int(dbytes / dn),
                 "launches_per_step": dn // args.steps, "avg_launch_ms": round(dms / dn, 4),
                 "share_of_step": round(dms / total_ms, 3),
                 "step_hbm_frac": round(sum(v[1] for v in fam.values()) / 1e6 / total_ms / HBM_PEAK_GBS, 4)}
