@@ -66,11 +66,16 @@ def stream():
 
 # When PROFILE is a list, every entry-point call is bracketed by HIP events on the current stream and
 # (name, algorithmic_bytes, start_event, end_event) is appended: bench.py turns that into per-kernel GB/s.
+# PROFILE_ONLY (a set of entry-point names, or None for all) restricts the bracketing: two event records per call cost
+# about 3.5 us of host time, which on a ~110-launch step is several per cent when every call is instrumented.
 PROFILE = None
+PROFILE_ONLY = None
 
 
 def call(name, *args, nbytes=0):
     prof = PROFILE
+    if prof is not None and PROFILE_ONLY is not None and name not in PROFILE_ONLY:
+        prof = None
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
