@@ -141,16 +141,19 @@ def main():
     for _ in range(max(args.warmup, 1)):
         model.train_step_fused(noisy, clean, opt, all_reduce)
     barrier()
+    nw = max(args.warmup, 1)
+    per_step = len(wprof) // nw
+    if nw > 1:                       # the first step pays one-time costs (code-object loads): leave it out of the table
+        wprof = wprof[per_step:]
+        nw -= 1
     wfam = families(wprof)
     wtotal = sum(v[0] for v in wfam.values())
     dom = max(wfam.items(), key=lambda kv: kv[1][0])[0]
-    step_bytes = sum(v[1] for v in wfam.values()) / max(args.warmup, 1)
+    step_bytes = sum(v[1] for v in wfam.values()) / nw
     if args.breakdown and rank == 0:
-        nw = max(args.warmup, 1)
         for name, (ms, nb, n) in sorted(wfam.items(), key=lambda kv: -kv[1][0]):
             print(f"{name:28s} {ms / nw:9.3f} ms/step {100 * ms / wtotal:5.1f}%  {n // nw:4d} calls  "
                   f"{nb / 1e6 / max(ms, 1e-9):9.1f} GB/s", file=sys.stderr)
-        per_step = len(wprof) // nw
         for i, (name, nbytes, e0, e1) in enumerate(wprof[-per_step:]):    # every launch of the last warm-up step
             ms = e0.elapsed_time(e1)
             print(f"  #{i:3d} {name:26s} {ms:7.3f} ms {nbytes / 1e6:9.1f} MB {nbytes / 1e6 / max(ms, 1e-9):8.1f} GB/s",

@@ -47,30 +47,72 @@ __device__ __forceinline__ float ln_row(float* row, int part, float eps) {
   return rstd;
 }
 
-// out[o] (o = part, part+4, ...) = sum_k x[k]*W[o*K+k] (+bias); x row and W in LDS.
-template <int K>
-__device__ __forceinline__ void row_linear(const float* xrow, const float* Wl, int O, int part, float* orow,
-                                           const float* bias, bool relu, const float* resid) {
-  float xr[K];
+// ---- fp32 MFMA (v_mfma_f32_16x16x4_f32) on LDS token tiles.  A tile holds TT = 64 tokens; wave w owns tokens
+// 16w..16w+15, the same tokens its threads own in the row-wise (4 lanes per token) steps.  Lane (p = lane & 15,
+// q = lane >> 4) feeds A[i = p][k = q] and B[k = q][j = p] and receives D[i = 4q + r][j = p], r = 0..3.
+
+// ot[t][o] = (sum_k xt[t][k] * Wl[o][k] + bias[o] + resid[t][o]), ReLU optional, for o < O and this wave's tokens.
+// K = 4*KSTEPS columns of xt must hold finite numbers; Wl is [O][wpitch]; MT = ceil(O / 16).
+template <int KSTEPS, int MT>
+__device__ __forceinline__ void tile_linear_mfma(const float* xt, int xpitch, const float* Wl, int wpitch, int O, float* ot,
+                                                 int opitch, const float* bias, bool relu, const float* resid,
+                                                 int rpitch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  f32x4 acc[MT];
+  int wrow[MT];
 #pragma unroll
-  for (int k = 0; k < K; k += 4) {
-    const float4 v = ld4(xrow + k);
-    xr[k] = v.x; xr[k + 1] = v.y; xr[k + 2] = v.z; xr[k + 3] = v.w;
+  for (int m = 0; m < MT; ++m) {
+    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wrow[m] = (16 * m + p < O ? 16 * m + p : O - 1) * wpitch + q;   // rows past O repeat the last one (discarded)
   }
-  for (int o = part; o < O; o += 4) {
-    float acc = bias ? bias[o] : 0.f;
-    const float* wr = Wl + o * WP;
+  const float* xr = xt + (16 * wave + p) * xpitch + q;
+#pragma unroll 4
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const float b = xr[4 * ks];
 #pragma unroll
-    for (int k = 0; k < K; k += 4) {
-      const float4 w = ld4(wr + k);
-      acc = fmaf(xr[k], w.x, acc);
-      acc = fmaf(xr[k + 1], w.y, acc);
-      acc = fmaf(xr[k + 2], w.z, acc);
-      acc = fmaf(xr[k + 3], w.w, acc);
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[wrow[m] + 4 * ks], b, acc[m], 0, 0, 0);
+  }
+  const int tok = 16 * wave + p;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * m + 4 * q + r;
+      if (o < O) {
+        float v = acc[m][r] + (bias ? bias[o] : 0.f);
+        if (resid) v += resid[tok * rpitch + o];
+        ot[tok * opitch + o] = relu ? fmaxf(v, 0.f) : v;
+      }
     }
-    if (resid) acc += resid[o];
-    orow[o] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+// acc[n] += sum_t dy[t][16m + i] * x[t][16n + j] over the 64 tokens of a tile (n < NT): the weight-gradient tiles
+// (m, 0..NT-1) of dW = dy^T x.
+template <int NT>
+__device__ __forceinline__ void tile_outer_mfma(f32x4 (&acc)[NT], const float* dy, int dpitch, int m, const float* x,
+                                                int xpitch) {
+  const int lane = threadIdx.x & 63, p = lane & 15, q = lane >> 4;
+  const float* dr = dy + q * dpitch + 16 * m + p;
+  const float* xr = x + q * xpitch + p;
+#pragma unroll 4
+  for (int s = 0; s < TT / 4; ++s) {
+    const float a = dr[4 * s * dpitch];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xr[4 * s * xpitch + 16 * n], acc[n], 0, 0, 0);
   }
+}
+
+// dst[(16m + i) * ldk + 16n + j] = acc[n] tile, rows < O and columns < K only
+template <int NT>
+__device__ __forceinline__ void store_outer_mfma(float* dst, int ldk, const f32x4 (&acc)[NT], int m, int O, int K) {
+  const int lane = threadIdx.x & 63, p = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * m + 4 * q + r, k = 16 * n + p;
+      if (o < O && k < K) dst[o * ldk + k] = acc[n][r];
+    }
 }
 
 __device__ __forceinline__ void tile_store(float* g, const float* tile, int pitch, long tok0, long ntok, int width) {
@@ -85,6 +127,15 @@ __device__ __forceinline__ void tile_load(float* tile, int pitch, const float* g
   for (int i = threadIdx.x; i < TT * width; i += 256) {
     const int t = i / width, c = i - t * width;
     tile[t * pitch + c] = (tok0 + t < ntok) ? g[(tok0 + t) * width + c] : 0.f;
+  }
+}
+
+// like tile_load, and columns [width, padded) are zeroed (they feed MFMA k-steps)
+__device__ __forceinline__ void tile_load_padded(float* tile, int pitch, const float* g, long tok0, long ntok, int width,
+                                                 int padded) {
+  for (int i = threadIdx.x; i < TT * padded; i += 256) {
+    const int t = i / padded, c = i - t * padded;
+    tile[t * pitch + c] = (tok0 + t < ntok && c < width) ? g[(tok0 + t) * width + c] : 0.f;
   }
 }
 
@@ -142,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
       row[c] = fmaf(row[c], lw[c], lw[D + c]);
     }
     __syncthreads();  // also orders the 4 lanes of a token (same wave) and the weight staging
-    row_linear<D>(row, Wl, O, part, os + t * O, nullptr, false, nullptr);
+    tile_linear_mfma<D / 4, 12>(xs, XS, Wl, WP, O, os, O, nullptr, false, nullptr, 0);
     __syncthreads();
     tile_store(qkv, os, O, tok0, d.ntok, O);
   }
@@ -526,17 +577,17 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
                                                             float* __restrict__ vad, AttnDims d) {
   extern __shared__ float lds[];
   const int HD = d.hd;
-  float* Wfc = lds;                 // [D][HD]
-  float* W1 = Wfc + D * D;          // [D][WP]
+  float* Wfc = lds;                 // [D][WP], columns >= HD zero
+  float* W1 = Wfc + D * WP;         // [D][WP]
   float* W2 = W1 + D * WP;          // [D][WP]
   float* vec = W2 + D * WP;         // ln0_w, ln0_b, ln1_w, ln1_b, b1, b2, ln2_w, ln2_b, vad_w  (9*D)
   float* ta = vec + 9 * D;          // [TT][XS]
   float* tb = ta + TT * XS;         // [TT][XS]
   float* tc = tb + TT * XS;         // [TT][XS]
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
-  for (int i = tid; i < D * HD; i += 256) Wfc[i] = P.fc[i];
   for (int i = tid; i < D * D; i += 256) {
     const int oo = i / D, k = i - oo * D;
+    Wfc[oo * WP + k] = k < HD ? P.fc[oo * HD + k] : 0.f;
     W1[oo * WP + k] = P.w1[i];
     W2[oo * WP + k] = P.w2[i];
   }
@@ -547,7 +598,7 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
   }
   for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
     __syncthreads();
-    tile_load(ta, XS, o, tok0, d.ntok, HD);       // ta = o
+    tile_load_padded(ta, XS, o, tok0, d.ntok, HD, D);   // ta = o, columns >= HD zero
     tile_load(tb, XS, xhat0, tok0, d.ntok, D);    // tb = xhat0 -> x1
     __syncthreads();
 #pragma unroll
@@ -556,16 +607,8 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
       tb[t * XS + c] = fmaf(tb[t * XS + c], vec[c], vec[D + c]);
     }
     __syncthreads();
-    // tc = y1 = o Wfc^T + x1   (K = HD, padded reads are avoided by the generic loop below)
-    {
-      float* orow = tc + t * XS;
-      const float* xrow = ta + t * XS;
-      for (int oo = part; oo < D; oo += 4) {
-        float acc = 0.f;
-        for (int k = 0; k < HD; ++k) acc = fmaf(xrow[k], Wfc[oo * HD + k], acc);
-        orow[oo] = acc + tb[t * XS + oo];
-      }
-    }
+    // tc = y1 = o Wfc^T + x1
+    tile_linear_mfma<D / 4, 4>(ta, XS, Wfc, WP, D, tc, XS, nullptr, false, tb, XS);
     __syncthreads();
     const bool valid = tok0 + t < d.ntok;
     float r1 = ln_row(tc + t * XS, part, 1e-6f);   // tc = xhat1
@@ -583,10 +626,10 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
       tc[t * XS + c] = fmaf(tc[t * XS + c], vec[2 * D + c], vec[3 * D + c]);   // tc = x2
     }
     __syncthreads();
-    row_linear<D>(tc + t * XS, W1, D, part, ta + t * XS, vec + 4 * D, true, nullptr);   // ta = hdn
+    tile_linear_mfma<D / 4, 4>(tc, XS, W1, WP, D, ta, XS, vec + 4 * D, true, nullptr, 0);   // ta = hdn
     __syncthreads();
     tile_store(hdn, ta, XS, tok0, d.ntok, D);
-    row_linear<D>(ta + t * XS, W2, D, part, tb + t * XS, vec + 5 * D, false, tc + t * XS);  // tb = y2
+    tile_linear_mfma<D / 4, 4>(ta, XS, W2, WP, D, tb, XS, vec + 5 * D, false, tc, XS);      // tb = y2
     __syncthreads();
     float r2 = ln_row(tb + t * XS, part, 1e-6f);   // tb = xhat2
     if (valid) {
@@ -609,25 +652,6 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
       vad[(tok0 + t) / d.n] = acc;
     }
   }
-}
-
-// dW[o0..o0+3][k0..k0+3] += sum_t dy[t][o] * x[t][k] over the tile (both tiles in LDS, pitch XS)
-__device__ __forceinline__ void acc_outer4(float (&a)[16], const float* dy, const float* x, int o0, int k0) {
-  for (int t = 0; t < TT; ++t) {
-    const float4 dv = ld4(dy + t * XS + o0);
-    const float4 xv = ld4(x + t * XS + k0);
-    a[0] = fmaf(dv.x, xv.x, a[0]); a[1] = fmaf(dv.x, xv.y, a[1]); a[2] = fmaf(dv.x, xv.z, a[2]); a[3] = fmaf(dv.x, xv.w, a[3]);
-    a[4] = fmaf(dv.y, xv.x, a[4]); a[5] = fmaf(dv.y, xv.y, a[5]); a[6] = fmaf(dv.y, xv.z, a[6]); a[7] = fmaf(dv.y, xv.w, a[7]);
-    a[8] = fmaf(dv.z, xv.x, a[8]); a[9] = fmaf(dv.z, xv.y, a[9]); a[10] = fmaf(dv.z, xv.z, a[10]); a[11] = fmaf(dv.z, xv.w, a[11]);
-    a[12] = fmaf(dv.w, xv.x, a[12]); a[13] = fmaf(dv.w, xv.y, a[13]); a[14] = fmaf(dv.w, xv.z, a[14]); a[15] = fmaf(dv.w, xv.w, a[15]);
-  }
-}
-
-__device__ __forceinline__ void store_outer4(float* dst, int ldk, const float (&a)[16], int o0, int k0) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[(o0 + r) * ldk + k0 + c] = a[r * 4 + c];
 }
 
 // LayerNorm backward on a tile: g (LDS, in/out: dL/d(ln out) -> dL/d(ln in)), xhat tile (LDS), gamma (LDS).
@@ -684,9 +708,9 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
   float* tc = tb + TT * XS;
   float* td = tc + TT * XS;
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
-  for (int i = tid; i < D * HD; i += 256) {
-    const int oo = i / HD, k = i - oo * HD;
-    WfcT[k * WP + oo] = P.fc[i];
+  for (int i = tid; i < D * D; i += 256) {     // rows k >= HD of the transposed fc weight are never read
+    const int oo = i / D, k = i - oo * D;
+    if (k < HD) WfcT[k * WP + oo] = P.fc[oo * HD + k];
   }
   for (int i = tid; i < D * D; i += 256) {
     const int oo = i / D, k = i - oo * D;
@@ -696,12 +720,12 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
   for (int i = tid; i < D; i += 256) {
     vec[i] = P.ln1_w[i]; vec[D + i] = P.ln2_w[i]; vec[2 * D + i] = P.vad_w[i]; vec[3 * D + i] = P.ln1_b[i];
   }
-  float aW2[16], aW1[16], aFc[16];
+  // weight gradients: wave w accumulates the 16 output rows 16w..16w+15 of each matrix (4 tiles of 16 columns)
+  const int wave = tid >> 6;
+  f32x4 aW2[4], aW1[4], aFc[4];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) aW2[e] = aW1[e] = aFc[e] = 0.f;
+  for (int e = 0; e < 4; ++e) aW2[e] = aW1[e] = aFc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dg2 = 0.f, db2ln = 0.f, dbias2 = 0.f, dbias1 = 0.f, dg1 = 0.f, db1ln = 0.f, dvw = 0.f, dvb = 0.f;
-  const int o0 = (tid >> 4) * 4, k0 = (tid & 15) * 4;      // 4x4 block of a DxD matrix
-  const bool fc_owner = k0 < HD;                            // HD is a multiple of 4
 
   for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
     __syncthreads();
@@ -734,9 +758,9 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
       for (int tt = 0; tt < TT; ++tt) s += ta[tt * XS + tid];
       dbias2 += s;
     }
-    acc_outer4(aW2, ta, tc, o0, k0);                                   // dW2 += dy2^T hdn
+    tile_outer_mfma<4>(aW2, ta, XS, wave, tc, XS);                     // dW2 += dy2^T hdn
     // td = d_pre = (dy2 W2) * [hdn > 0]
-    row_linear<D>(ta + t * XS, W2T, D, part, td + t * XS, nullptr, false, nullptr);
+    tile_linear_mfma<D / 4, 4>(ta, XS, W2T, WP, D, td, XS, nullptr, false, nullptr, 0);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < D / 4; ++k) {
@@ -758,26 +782,26 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
       tc[t * XS + c] = fmaf(tb[t * XS + c], vec[c], vec[3 * D + c]);
     }
     __syncthreads();
-    acc_outer4(aW1, td, tc, o0, k0);                                   // dW1 += d_pre^T x2
+    tile_outer_mfma<4>(aW1, td, XS, wave, tc, XS);                     // dW1 += d_pre^T x2
     __syncthreads();
     // tc = d_x2 = dy2 + d_pre W1
-    row_linear<D>(td + t * XS, W1T, D, part, tc + t * XS, nullptr, false, ta + t * XS);
+    tile_linear_mfma<D / 4, 4>(td, XS, W1T, WP, D, tc, XS, nullptr, false, ta, XS);
     __syncthreads();
     ln_bwd_tile(tc, tb, vec, rstd1, tok0, d.ntok, dg1, db1ln);        // tc = dy1
     __syncthreads();
     tile_store(d_x1, tc, XS, tok0, d.ntok, D);                          // residual branch of x1
-    tile_load(ta, XS, o, tok0, d.ntok, HD);                             // ta = o (cols >= HD are stale: masked below)
+    tile_load_padded(ta, XS, o, tok0, d.ntok, HD, D);                   // ta = o, columns >= HD zero
     __syncthreads();
-    if (fc_owner) acc_outer4(aFc, tc, ta, o0, k0);                      // dWfc += dy1^T o
+    tile_outer_mfma<4>(aFc, tc, XS, wave, ta, XS);                      // dWfc += dy1^T o
     // td = d_o = dy1 Wfc  (HD outputs)
-    row_linear<D>(tc + t * XS, WfcT, HD, part, td + t * XS, nullptr, false, nullptr);
+    tile_linear_mfma<D / 4, 4>(tc, XS, WfcT, WP, HD, td, XS, nullptr, false, nullptr, 0);
     __syncthreads();
     tile_store(d_o, td, XS, tok0, d.ntok, HD);
   }
   float* row = slab + (size_t)blockIdx.x * (2 * D * D + D * HD + 7 * D + 1);
-  store_outer4(row, D, aW2, o0, k0);
-  store_outer4(row + D * D, D, aW1, o0, k0);
-  if (fc_owner) store_outer4(row + 2 * D * D, HD, aFc, o0, k0);
+  store_outer_mfma<4>(row, D, aW2, wave, D, D);
+  store_outer_mfma<4>(row + D * D, D, aW1, wave, D, D);
+  store_outer_mfma<4>(row + 2 * D * D, HD, aFc, wave, D, HD);
   if (tid < D) {
     float* v = row + 2 * D * D + D * HD;
     v[tid] = dg2; v[D + tid] = db2ln; v[2 * D + tid] = dbias2; v[3 * D + tid] = dbias1;
@@ -796,84 +820,61 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(const float* __restri
                                                            float* __restrict__ slab, AttnDims d) {
   extern __shared__ float lds[];
   const int O = 3 * d.hd;
-  float* Wl = lds;                  // [O][D] (row o = output feature o of the fused qkv projection)
-  float* dq = Wl + O * D;           // [TT][O]
-  float* ta = dq + TT * O;          // [TT][XS]
+  constexpr int OP = 3 * D + 4;     // pitch of the O-wide tiles (O <= 192), = 4 mod 64 banks
+  float* WT = lds;                  // [D][OP]: WT[k][o] = Wqkv[o][k], columns >= O zero
+  float* dq = WT + D * OP;          // [TT][OP], columns >= O zero
+  float* ta = dq + TT * OP;         // [TT][XS]
   float* tb = ta + TT * XS;
-  float* lw = tb + TT * XS;         // [2][D]
-  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
-  for (int i = tid; i < O * D; i += 256) {
-    const int o = i / D, k = i - o * D;
-    const int which = o / d.hd, oo = o - which * d.hd;
-    const float* w = which == 0 ? wq : (which == 1 ? wk : wv);
-    Wl[i] = w[oo * D + k];
+  float* tc = tb + TT * XS;
+  float* lw = tc + TT * XS;         // [2][D]
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3, wave = tid >> 6;
+  for (int i = tid; i < D * 3 * D; i += 256) {
+    const int k = i / (3 * D), o = i - k * (3 * D);
+    float v = 0.f;
+    if (o < O) {
+      const int which = o / d.hd, oo = o - which * d.hd;
+      const float* w = which == 0 ? wq : (which == 1 ? wk : wv);
+      v = w[oo * D + k];
+    }
+    WT[k * OP + o] = v;
   }
   for (int i = tid; i < D; i += 256) {
     lw[i] = ln_w[i];
     lw[D + i] = ln_b[i];
   }
-  // each thread owns 4x4 blocks of dWqkv: block id = tid, tid+256, ... over (O/4) x (D/4) blocks
-  const int nblk = (O / 4) * (D / 4);
-  constexpr int MAXB = 4;
-  float aW[MAXB][16];
+  // dWqkv (O x D): wave w accumulates the row tiles w, w+4, w+8 (16 output features each, 4 tiles of 16 columns)
+  f32x4 aW[3][4];
 #pragma unroll
-  for (int r = 0; r < MAXB; ++r)
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) aW[r][e] = 0.f;
+    for (int e = 0; e < 4; ++e) aW[r][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dg0 = 0.f, db0 = 0.f;
 
   for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
     __syncthreads();
-    tile_load(dq, O, d_qkv, tok0, d.ntok, O);
+    tile_load_padded(dq, OP, d_qkv, tok0, d.ntok, O, 3 * D);
     tile_load(ta, XS, d_x1, tok0, d.ntok, D);     // ta = d_x1 (residual part)
     tile_load(tb, XS, xhat0, tok0, d.ntok, D);    // tb = xhat0
     __syncthreads();
+    // tc = x1 = ln_w*xhat0 + ln_b
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      tc[t * XS + c] = fmaf(tb[t * XS + c], lw[c], lw[D + c]);
+    }
     // ta += d_qkv Wqkv
-    {
-      float acc[D / 4];
-#pragma unroll
-      for (int k = 0; k < D / 4; ++k) acc[k] = ta[t * XS + part * (D / 4) + k];
-      for (int o = 0; o < O; ++o) {
-        const float g = dq[t * O + o];
-#pragma unroll
-        for (int k = 0; k < D / 4; ++k) acc[k] = fmaf(g, Wl[o * D + part * (D / 4) + k], acc[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < D / 4; ++k) ta[t * XS + part * (D / 4) + k] = acc[k];
-    }
-    // dWqkv += d_qkv^T x1, x1 = ln_w*xhat0 + ln_b
-#pragma unroll
-    for (int r = 0; r < MAXB; ++r) {
-      const int blk = tid + r * 256;
-      if (blk < nblk) {
-        const int o0 = (blk / (D / 4)) * 4, k0 = (blk % (D / 4)) * 4;
-        for (int tt = 0; tt < TT; ++tt) {
-          const float4 dv = ld4(dq + tt * O + o0);
-          float4 xv = ld4(tb + tt * XS + k0);
-          xv = fma4(xv, ld4(lw + k0), ld4(lw + D + k0));
-          if (tok0 + tt >= d.ntok) xv = f4(0.f);
-          float* a = aW[r];
-          a[0] = fmaf(dv.x, xv.x, a[0]); a[1] = fmaf(dv.x, xv.y, a[1]); a[2] = fmaf(dv.x, xv.z, a[2]); a[3] = fmaf(dv.x, xv.w, a[3]);
-          a[4] = fmaf(dv.y, xv.x, a[4]); a[5] = fmaf(dv.y, xv.y, a[5]); a[6] = fmaf(dv.y, xv.z, a[6]); a[7] = fmaf(dv.y, xv.w, a[7]);
-          a[8] = fmaf(dv.z, xv.x, a[8]); a[9] = fmaf(dv.z, xv.y, a[9]); a[10] = fmaf(dv.z, xv.z, a[10]); a[11] = fmaf(dv.z, xv.w, a[11]);
-          a[12] = fmaf(dv.w, xv.x, a[12]); a[13] = fmaf(dv.w, xv.y, a[13]); a[14] = fmaf(dv.w, xv.z, a[14]); a[15] = fmaf(dv.w, xv.w, a[15]);
-        }
-      }
-    }
+    tile_linear_mfma<3 * D / 4, 4>(dq, OP, WT, OP, D, ta, XS, nullptr, false, ta, XS);
     __syncthreads();
+    // dWqkv += d_qkv^T x1   (rows of padded tokens are zero in dq)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tile_outer_mfma<4>(aW[r], dq, OP, wave + 4 * r, tc, XS);
     ln_bwd_tile(ta, tb, lw, rstd0, tok0, d.ntok, dg0, db0);
     __syncthreads();
     tile_store(d_x0, ta, XS, tok0, d.ntok, D);
   }
   float* row = slab + (size_t)blockIdx.x * (O * D + 2 * D);
 #pragma unroll
-  for (int r = 0; r < MAXB; ++r) {
-    const int blk = tid + r * 256;
-    if (blk < nblk) {
-      const int o0 = (blk / (D / 4)) * 4, k0 = (blk % (D / 4)) * 4;
-      store_outer4(row, D, aW[r], o0, k0);
-    }
-  }
+  for (int r = 0; r < 3; ++r) store_outer_mfma<4>(row, D, aW[r], wave + 4 * r, O, D);
   if (tid < D) {
     row[O * D + tid] = dg0;
     row[O * D + D + tid] = db0;
@@ -914,7 +915,7 @@ NOISE_EXPORT int noise_attn_pre_fwd(const float* x_y, const float* x_coef, int x
   const size_t smem = (size_t)(O * WP + TT * XS + TT * O + 2 * D) * sizeof(float);
   LazySrc X{x_y, x_coef, x_relu6};
   NOISE_ALLOW_LDS(attn_pre_fwd_kernel, smem);
-  hipLaunchKernelGGL(attn_pre_fwd_kernel, dim3(noise_grid(ntok, TT, 1024)), dim3(256), smem, (hipStream_t)stream, X, ln_w,
+  hipLaunchKernelGGL(attn_pre_fwd_kernel, dim3(noise_grid(ntok, TT, ATTN_MAX_BLOCKS)), dim3(256), smem, (hipStream_t)stream, X, ln_w,
                      ln_b, wq, wk, wv, xhat0, rstd0, qkv, d);
   NOISE_CHECK_LAUNCH("noise_attn_pre_fwd");
   return 0;
@@ -991,9 +992,9 @@ NOISE_EXPORT int noise_attn_post_fwd(const float* o, const float* xhat0, const f
                 "noise_attn_post_fwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   PostParams P{fc, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, vad_w, vad_b};
-  const size_t smem = (size_t)(D * D + 2 * D * WP + 9 * D + 3 * TT * XS) * sizeof(float);
+  const size_t smem = (size_t)(3 * D * WP + 9 * D + 3 * TT * XS) * sizeof(float);
   NOISE_ALLOW_LDS(attn_post_fwd_kernel, smem);
-  hipLaunchKernelGGL(attn_post_fwd_kernel, dim3(noise_grid(ntok, TT, 1024)), dim3(256), smem, (hipStream_t)stream, o, xhat0,
+  hipLaunchKernelGGL(attn_post_fwd_kernel, dim3(noise_grid(ntok, TT, ATTN_MAX_BLOCKS)), dim3(256), smem, (hipStream_t)stream, o, xhat0,
                      ln0_w, ln0_b, P, xhat1, rstd1, hdn, xhat2, rstd2, x3, vad, d);
   NOISE_CHECK_LAUNCH("noise_attn_post_fwd");
   return 0;
@@ -1039,7 +1040,7 @@ NOISE_EXPORT int noise_attn_pre_bwd(const float* d_qkv, const float* d_x1, const
   NOISE_REQUIRE((O / 4) * (D / 4) <= 4 * 256, "noise_attn_pre_bwd: projection too wide");
   const int ncols = O * D + 2 * D;
   const int grid = noise_grid(ntok, TT, ATTN_MAX_BLOCKS);
-  const size_t smem = (size_t)(O * D + TT * O + 2 * TT * XS + 2 * D) * sizeof(float);
+  const size_t smem = (size_t)((D + TT) * (3 * D + 4) + 3 * TT * XS + 2 * D) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   NOISE_ALLOW_LDS(attn_pre_bwd_kernel, smem);
   hipLaunchKernelGGL(attn_pre_bwd_kernel, dim3(grid), dim3(256), smem, st, d_qkv, d_x1, xhat0, rstd0, ln_w, ln_b, wq, wk, wv,
