@@ -610,8 +610,13 @@ NOISE_EXPORT int noise_first_conv_fwd(const float* logmag, const float* absmax, 
   if (sy == 2 && sx == 2) {
     FirstWalkDims wd{B, H, W, hp, wp, d.Ho, d.Wo, C, pad_value, 0, 0, 0};
     first_walk_plan(wd, noise_conv_max_blocks(), grid);
-    hipLaunchKernelGGL(first_walk_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
-                       (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
+    const int CG = C / 4;
+    if (CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64)
+      hipLaunchKernelGGL(first_walk_fwd_kernel<true>, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
+                         (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
+    else
+      hipLaunchKernelGGL(first_walk_fwd_kernel<false>, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
+                         (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
   } else {
     hipLaunchKernelGGL(first_conv_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
                        (hipStream_t)stream, logmag, absmax, w, out, stats_slab, d);
@@ -634,8 +639,13 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
   if (sy == 2 && sx == 2) {
     FirstWalkDims wd{B, H, W, hp, wp, d.Ho, d.Wo, C, pad_value, 0, 0, 0};
     first_walk_plan(wd, noise_conv_max_blocks(), grid);
-    hipLaunchKernelGGL(first_walk_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
-                       absmax, scratch, wd);
+    const int CG = C / 4;
+    if (CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64)
+      hipLaunchKernelGGL(first_walk_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G,
+                         logmag, absmax, scratch, wd);
+    else
+      hipLaunchKernelGGL(first_walk_wgrad_kernel<false>, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G,
+                         logmag, absmax, scratch, wd);
   } else {
     hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
                        absmax, scratch, d);

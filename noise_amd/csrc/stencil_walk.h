@@ -721,8 +721,36 @@ struct FirstWindow {
       r[j] = (rin && cin) ? ((rdata && cdata) ? v : pad_value) : 0.f;
     }
   }
+  // one element of the window: padded row py, tap column j
+  __device__ __forceinline__ float at(int py, int j) const {
+    const int y = py - hp, px = px0 + j, xx = px - wp;
+    const bool rin = py >= 0 && py < H + hp, rdata = y >= 0 && rin;
+    const bool cin = px >= 0 && px < W + wp, cdata = xx >= 0 && cin;
+    const float v = x[(size_t)(rdata ? y : 0) * W + (cdata ? xx : 0)] / mx;
+    return (rin && cin) ? ((rdata && cdata) ? v : pad_value) : 0.f;
+  }
+  // The two new rows of a stride-2 step (padded rows py, py + 1).  With COOP (C/4 a power of two >= 8: the lanes of a
+  // column are 8+ consecutive lanes of one wave) lane cg < 6 fetches and normalises element (cg / 3, cg % 3) and
+  // the six values are exchanged with lane shuffles: one load and one division per lane instead of six.
+  template <bool COOP>
+  __device__ __forceinline__ void rows2(int py, int cg, int CG, float (&r1)[3], float (&r2)[3]) const {
+    if (COOP) {
+      const int e = cg < 6 ? cg : 0;
+      const float mine = at(py + e / 3, e % 3);
+      const int base = (int)(threadIdx.x & 63) & ~(CG - 1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        r1[j] = __shfl(mine, base + j, 64);
+        r2[j] = __shfl(mine, base + 3 + j, 64);
+      }
+    } else {
+      row(py, r1);
+      row(py + 1, r2);
+    }
+  }
 };
 
+template <bool COOP>
 __global__ __launch_bounds__(256) void first_walk_fwd_kernel(const float* __restrict__ x, const float* __restrict__ absmax,
                                                              const float* __restrict__ w, float* __restrict__ out,
                                                              float* __restrict__ slab, FirstWalkDims d) {
@@ -746,8 +774,7 @@ __global__ __launch_bounds__(256) void first_walk_fwd_kernel(const float* __rest
       win.row(2 * r0 - 1, t0);
       float* o = out + (((size_t)bi * d.Ho + r0) * d.Wo + ox) * C + c;
       for (int oy = r0; oy < r1; ++oy, o += (size_t)d.Wo * C) {
-        win.row(2 * oy, t1);
-        win.row(2 * oy + 1, t2);
+        win.template rows2<COOP>(2 * oy, cg, CG, t1, t2);
         float4 acc = f4(t0[0]) * wk[0];
         acc = fma4(f4(t0[1]), wk[1], acc);
         acc = fma4(f4(t0[2]), wk[2], acc);
@@ -772,6 +799,7 @@ __global__ __launch_bounds__(256) void first_walk_fwd_kernel(const float* __rest
 }
 
 // dW[c][k] = sum_o dy[o][c] * x_in(2o - 1 + k)   (the input is data: no input gradient)
+template <bool COOP>
 __global__ __launch_bounds__(256) void first_walk_wgrad_kernel(LazyGrad G, const float* __restrict__ x,
                                                                const float* __restrict__ absmax,
                                                                float* __restrict__ dw_slab, FirstWalkDims d) {
@@ -796,8 +824,7 @@ __global__ __launch_bounds__(256) void first_walk_wgrad_kernel(LazyGrad G, const
       win.row(2 * r0 - 1, t0);
       size_t off = (((size_t)bi * d.Ho + r0) * d.Wo + ox) * C + c;
       for (int oy = r0; oy < r1; ++oy, off += (size_t)d.Wo * C) {
-        win.row(2 * oy, t1);
-        win.row(2 * oy + 1, t2);
+        win.template rows2<COOP>(2 * oy, cg, CG, t1, t2);
         const float4 dy = lazygrad4_at(gr, off);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
