@@ -714,18 +714,22 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
     last_walk_plan(wd, false, noise_conv_max_blocks(), grid);
     const size_t sm = (size_t)PPB * 12 * C * sizeof(float);
     const bool hb = b_y != nullptr, hg = g_other != nullptr;
-    if (hb && hg)
-      hipLaunchKernelGGL((last_gather_bwd_kernel<true, true>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
-                         g_in, scratch, E, wd);
-    else if (hb)
-      hipLaunchKernelGGL((last_gather_bwd_kernel<true, false>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
-                         g_in, scratch, E, wd);
-    else if (hg)
-      hipLaunchKernelGGL((last_gather_bwd_kernel<false, true>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
-                         g_in, scratch, E, wd);
-    else
-      hipLaunchKernelGGL((last_gather_bwd_kernel<false, false>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, Bs, w,
-                         g_in, scratch, E, wd);
+    const int CG = C / 4;
+    const bool coop = CG >= 8 && CG <= 64 && (CG & (CG - 1)) == 0;
+#define LAUNCH_LAST(HB, HG)                                                                                        \
+  do {                                                                                                             \
+    if (coop)                                                                                                      \
+      hipLaunchKernelGGL((last_gather_bwd_kernel<HB, HG, true>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, \
+                         Bs, w, g_in, scratch, E, wd);                                                             \
+    else                                                                                                           \
+      hipLaunchKernelGGL((last_gather_bwd_kernel<HB, HG, false>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, \
+                         Bs, w, g_in, scratch, E, wd);                                                             \
+  } while (0)
+    if (hb && hg) LAUNCH_LAST(true, true);
+    else if (hb) LAUNCH_LAST(true, false);
+    else if (hg) LAUNCH_LAST(false, true);
+    else LAUNCH_LAST(false, false);
+#undef LAUNCH_LAST
   } else {
     hipLaunchKernelGGL(last_convT_bwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 12 * C * sizeof(float), st, d_enh, enh,
                        absmax, A, Bs, w, g_in, scratch, E, d);

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc B
 // backward: dy0(Y, X) = d_enh * max * [|enh| < max] inside the crop, 0 outside;
 //   g_in[i][c] = sum_k dy0(2i - 1 + k) * w[c][k];   dW[c][k] += a[i][c] * dy0(2i - 1 + k);   db = sum dy0
 // Slab rows are 12*C floats: 9 taps | bias gradient at column 9*C | producer BatchNorm sums at [10C, 12C).
-template <bool HAS_B, bool HAS_GO>
+template <bool HAS_B, bool HAS_GO, bool COOP>
 __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __restrict__ d_enh, const float* __restrict__ enh,
                                                               const float* __restrict__ absmax, LazySrc A, LazySrc Bsrc,
                                                               const float* __restrict__ w, float* __restrict__ g_in,
@@ -606,19 +606,32 @@ __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __res
       size_t ioff = (((size_t)bi * d.Hi + r0) * d.Wi + ix) * C + c;
       const size_t drow = (size_t)d.Wi * C;
       // software pipeline (see walk_gather_bwd_kernel): the next input row's operands are requested first
-      float re[2][3], rg[2][3];
+      // COOP (C/4 a power of two >= 8): lane cg < 6 of a column fetches enh / d_enh of window element (cg / 3, cg % 3) and
+      // forms its dy0; the six values are exchanged with lane shuffles (2 scalar loads per lane instead of 12).
+      float re[COOP ? 1 : 2][COOP ? 1 : 3], rg[COOP ? 1 : 2][COOP ? 1 : 3];
       float4 ray, rby, rgo;
+      const int ce = cg < 6 ? cg : 0, cu = ce / 3, cj = ce - 3 * cu;
+      const int ccol = cj == 0 ? c0 : (cj == 1 ? c1 : c2);
+      const bool cval = cj == 0 ? v0 : (cj == 1 ? v1 : v2);
+      const int gbase = (int)(threadIdx.x & 63) & ~(CG - 1);
       auto issue = [&](int iy, size_t off) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int Y = 2 * iy + u - d.oy0;
+        if (COOP) {
+          const int Y = 2 * iy + cu - d.oy0;
           const size_t row = oclip + (size_t)((Y >= 0 && Y < d.H) ? Y : 0) * d.W;
-          re[u][0] = enh[row + c0];
-          re[u][1] = enh[row + c1];
-          re[u][2] = enh[row + c2];
-          rg[u][0] = d_enh[row + c0];
-          rg[u][1] = d_enh[row + c1];
-          rg[u][2] = d_enh[row + c2];
+          re[0][0] = enh[row + ccol];
+          rg[0][0] = d_enh[row + ccol];
+        } else {
+#pragma unroll
+          for (int u = 0; u < (COOP ? 0 : 2); ++u) {
+            const int Y = 2 * iy + u - d.oy0;
+            const size_t row = oclip + (size_t)((Y >= 0 && Y < d.H) ? Y : 0) * d.W;
+            re[u][0] = enh[row + c0];
+            re[u][COOP ? 0 : 1] = enh[row + c1];
+            re[u][COOP ? 0 : 2] = enh[row + c2];
+            rg[u][0] = d_enh[row + c0];
+            rg[u][COOP ? 0 : 1] = d_enh[row + c1];
+            rg[u][COOP ? 0 : 2] = d_enh[row + c2];
+          }
         }
         ray = ld4(px.a.y + off);
         rby = HAS_B ? ld4(px.b.y + off) : f4(0.f);
@@ -629,12 +642,24 @@ __global__ __launch_bounds__(256) void last_gather_bwd_kernel(const float* __res
       for (int iy = r0; iy < r1; ++iy, ioff += drow) {
         const int Y1 = 2 * iy - d.oy0, Y2 = Y1 + 1;
         const bool vy1 = Y1 >= 0 && Y1 < d.H, vy2 = Y2 >= 0 && Y2 < d.H;
-        t1[0] = (vy1 && v0 && re[0][0] > -mxv && re[0][0] < mxv) ? rg[0][0] * mxv : 0.f;
-        t1[1] = (vy1 && v1 && re[0][1] > -mxv && re[0][1] < mxv) ? rg[0][1] * mxv : 0.f;
-        t1[2] = (vy1 && v2 && re[0][2] > -mxv && re[0][2] < mxv) ? rg[0][2] * mxv : 0.f;
-        t2[0] = (vy2 && v0 && re[1][0] > -mxv && re[1][0] < mxv) ? rg[1][0] * mxv : 0.f;
-        t2[1] = (vy2 && v1 && re[1][1] > -mxv && re[1][1] < mxv) ? rg[1][1] * mxv : 0.f;
-        t2[2] = (vy2 && v2 && re[1][2] > -mxv && re[1][2] < mxv) ? rg[1][2] * mxv : 0.f;
+        if (COOP) {
+          const bool vy = cu == 0 ? vy1 : vy2;
+          const float mine = (vy && cval && re[0][0] > -mxv && re[0][0] < mxv) ? rg[0][0] * mxv : 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            t1[j] = __shfl(mine, gbase + j, 64);
+            t2[j] = __shfl(mine, gbase + 3 + j, 64);
+          }
+        } else {
+          t1[0] = (vy1 && v0 && re[0][0] > -mxv && re[0][0] < mxv) ? rg[0][0] * mxv : 0.f;
+          t1[1] = (vy1 && v1 && re[0][COOP ? 0 : 1] > -mxv && re[0][COOP ? 0 : 1] < mxv) ? rg[0][COOP ? 0 : 1] * mxv : 0.f;
+          t1[2] = (vy1 && v2 && re[0][COOP ? 0 : 2] > -mxv && re[0][COOP ? 0 : 2] < mxv) ? rg[0][COOP ? 0 : 2] * mxv : 0.f;
+          t2[0] = (vy2 && v0 && re[COOP ? 0 : 1][0] > -mxv && re[COOP ? 0 : 1][0] < mxv) ? rg[COOP ? 0 : 1][0] * mxv : 0.f;
+          t2[1] = (vy2 && v1 && re[COOP ? 0 : 1][COOP ? 0 : 1] > -mxv && re[COOP ? 0 : 1][COOP ? 0 : 1] < mxv)
+                      ? rg[COOP ? 0 : 1][COOP ? 0 : 1] * mxv : 0.f;
+          t2[2] = (vy2 && v2 && re[COOP ? 0 : 1][COOP ? 0 : 2] > -mxv && re[COOP ? 0 : 1][COOP ? 0 : 2] < mxv)
+                      ? rg[COOP ? 0 : 1][COOP ? 0 : 2] * mxv : 0.f;
+        }
         const float4 yraw = ray;
         float4 av = lazy4_act(px.a, yraw);
         if (HAS_B) av = av + lazy4_act(px.b, rby);
