@@ -564,6 +564,86 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// B'': the core without dropout (inference, validation) for clips of any length: fp32 MFMA tiles with an online
+// softmax, so the n x n scores are never materialised and never recomputed.  K and V of one (clip, head) live in
+// LDS; a wave owns 16 queries and walks the keys 16 at a time:
+//     S^T tile [key][query] = K Q^T              (DK4 MFMAs; a lane gets 4 keys of one query)
+//     running max / rescale / p = exp(s - m)     (row maximum across the 4 lane groups by two shuffles)
+//     O^T [d][query] += V^T P^T                  (4 MFMAs; MFMA k-step s takes key 4*q + s, i.e. the lane's own
+//                                                 register s, so P goes from one MFMA to the next without moving)
+template <int DK4>
+__global__ __launch_bounds__(256) void attn_core_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                 float* __restrict__ ml, AttnDims d, int nsplit) {
+  extern __shared__ float lds[];
+  constexpr int DKP = DK4 * 4;
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int ntile = (n + 15) >> 4, n16 = ntile * 16;
+  const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit;
+  const int b = bh / d.heads, h = bh % d.heads;
+  float* ks = lds;                   // [n16][DKP], rows >= n zero
+  float* vs = ks + n16 * DKP;        // [n16 + 1][DKP] (one spare row: lanes d >= DKP read past a row)
+  const long base = (long)b * n;
+  for (int i = threadIdx.x; i < (n16 + 1) * DKP; i += 256) {
+    const int j = i / DKP, c = i - j * DKP;
+    const bool in = j < n && c < dk;
+    if (j < n16) ks[i] = in ? qkv[(base + j) * O + d.hd + h * dk + c] : 0.f;
+    vs[i] = in ? qkv[(base + j) * O + 2 * d.hd + h * dk + c] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  const float temp = sqrtf((float)dk);
+  for (int qt = split * 4 + wave; qt < ntile; qt += 4 * nsplit) {
+    const int qi = qt * 16 + p;
+    const bool valid = qi < n;
+    const float* qrow = qkv + (base + (valid ? qi : n - 1)) * O + h * dk;
+    float qreg[DK4];
+#pragma unroll
+    for (int kk = 0; kk < DK4; ++kk) qreg[kk] = (4 * kk + q < dk) ? qrow[4 * kk + q] / temp : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int kb = 0; kb < ntile; ++kb) {
+      const int key0 = kb * 16;
+      f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk)
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[(key0 + p) * DKP + 4 * kk + q], qreg[kk], st, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (key0 + 4 * q + r >= n) st[r] = -INFINITY;
+      float bm = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m, bm);          // finite: every block holds at least one real key
+      const float sc = expf(m - mn);
+      float pr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[r] = expf(st[r] - mn);
+      l = l * sc + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] *= sc;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[(key0 + 4 * q + s2) * DKP + p], pr[s2], acc, 0, 0, 0);
+      m = mn;
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (valid) {
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * q + r;
+        if (c < dk) o[(base + qi) * d.hd + h * dk + c] = acc[r] * inv;
+      }
+      if (ml && q == 0) {
+        ml[(((long)b * d.heads + h) * n + qi) * 2] = m;
+        ml[(((long)b * d.heads + h) * n + qi) * 2 + 1] = l;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // C: o, x1 -> y1 = o Wfc^T + x1 -> xhat1 -> x2 -> hdn = relu(x2 W1^T + b1) -> y2 = hdn W2^T + b2 + x2 -> xhat2 -> x3
 struct PostParams {
   const float *fc, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b, *vad_w, *vad_b;
@@ -941,6 +1021,26 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
     X(1) X(2) X(3) X(4)
 #undef X
     NOISE_CHECK_LAUNCH("noise_attn_core_fwd/wave");
+    return 0;
+  }
+  if (keep == nullptr && p_drop == 0.f) {   // no dropout: MFMA tiles with an online softmax
+    const int dk4 = (dk + 3) / 4, n16 = (n + 15) / 16 * 16;
+    const size_t sm = (size_t)(2 * n16 + 1) * dk4 * 4 * sizeof(float);
+    NOISE_REQUIRE(sm <= 158 * 1024, "noise_attn_core_fwd: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
+    const long bh = (ntok / n) * heads;
+    int nsplit = (int)(1024 / bh);
+    const int max_split = (n16 / 16 + 3) / 4;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    const dim3 grid((unsigned)(bh * nsplit));
+#define X(K4)                                                                                                      \
+  if (dk4 == K4) {                                                                                                 \
+    NOISE_ALLOW_LDS(attn_core_fwd_mfma_kernel<K4>, sm);                                                            \
+    hipLaunchKernelGGL(attn_core_fwd_mfma_kernel<K4>, grid, dim3(256), sm, (hipStream_t)stream, qkv, o, ml, d, nsplit); \
+  }
+    X(1) X(2) X(3) X(4)
+#undef X
+    NOISE_CHECK_LAUNCH("noise_attn_core_fwd/mfma");
     return 0;
   }
   const size_t smem = (size_t)2 * n * dk * sizeof(float);

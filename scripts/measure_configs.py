@@ -1,0 +1,56 @@
+"""Throughput of the other BASELINE configurations on one MI355X (for the design notes; bench.py measures the
+training step): eval forward of 10 s clips at A (320/160) and B (512/128), STFT feature generation, mixing."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from noise_amd import VADSpectralV2, mixer
+from noise_amd.data import synth_batch
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps=5):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+out = {}
+for tag, n_fft, hop in (("A", 320, 160), ("B", 512, 128)):
+    torch.manual_seed(0)
+    m = VADSpectralV2(n_fft=n_fft, hop_length=hop, win_length=n_fft, window="hann", nhead=6, num_layers=1, dropout=0.0,
+                      layer_config=[list(r) for r in bench.LAYER_CONFIG], pad_value=-1, max_frames=1300).to(dev).eval()
+    for B in (8, 64, 256):
+        x, _, _ = synth_batch(B, 160000, dev, seed=7)
+        with torch.no_grad():
+            dt = timed(lambda: m(x.view(B, 1, 1, -1)), reps=3)
+        out[f"forward_{tag}_B{B}x10s"] = round(B * 10 / dt, 1)
+    x, _, _ = synth_batch(256, 160000, dev, seed=7)
+    with torch.no_grad():
+        dt = timed(lambda: m.stft.forward(x.view(256, 1, 1, -1)))
+    out[f"stft_{tag}_B256x10s"] = round(2560 / dt, 1)
+    del m
+    torch.cuda.empty_cache()
+# streaming window: (N,1,1,8000) forward, 0.2 s of new audio per stream per step
+torch.manual_seed(0)
+m = bench.build_model(dev).eval()
+for N in (1, 1024):
+    x, _, _ = synth_batch(N, 8000, dev, seed=9)
+    with torch.no_grad():
+        dt = timed(lambda: m(x.view(N, 1, 1, -1)), reps=20)
+    out[f"window_forward_A_N{N}"] = {"ms_per_step": round(1000 * dt, 3), "audio_s_per_s": round(N * 0.2 / dt, 1)}
+# mixing: U utterances of 10 s, float64
+U, L = 1024, 160000
+g = torch.Generator(device="cpu").manual_seed(3)
+clean = (torch.randn(U, L, generator=g, dtype=torch.float64) * 0.05).to(dev)
+noise = (torch.randn(U, L, generator=g, dtype=torch.float64) * 0.02).to(dev)
+snr = torch.randint(-5, 20, (U,), generator=g).to(dev)
+level = torch.randint(-35, -15, (U,), generator=g).to(dev)
+dt = timed(lambda: mixer.mix_batch(clean, noise, snr, level))
+out["mix_1024x10s_f64"] = {"audio_s_per_s": round(U * 10 / dt, 1), "GB_per_s": round(56 * L * U / dt / 1e9, 1)}
+print(json.dumps(out, indent=1))
