@@ -44,6 +44,13 @@ for N in (1, 1024):
     with torch.no_grad():
         dt = timed(lambda: m(x.view(N, 1, 1, -1)), reps=20)
     out[f"window_forward_A_N{N}"] = {"ms_per_step": round(1000 * dt, 3), "audio_s_per_s": round(N * 0.2 / dt, 1)}
+    run = m.graphed_forward(x.view(N, 1, 1, -1))
+    ref = m(x.view(N, 1, 1, -1)).clone()
+    got = run(x.view(N, 1, 1, -1))
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got), "graph replay differs from the eager forward"
+    dt = timed(lambda: run(x.view(N, 1, 1, -1)), reps=50)
+    out[f"window_forward_A_N{N}_hipgraph"] = {"ms_per_step": round(1000 * dt, 3), "audio_s_per_s": round(N * 0.2 / dt, 1)}
 # mixing: U utterances of 10 s, float64
 U, L = 1024, 160000
 g = torch.Generator(device="cpu").manual_seed(3)

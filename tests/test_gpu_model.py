@@ -55,6 +55,21 @@ def test_eval_forward_golden(dev, golden_dir, tag, n_fft, hop):
         np.testing.assert_allclose(out.cpu().numpy(), g[f"{s}_out"], atol=1e-4)
 
 
+def test_graphed_forward_matches_eager(dev, golden_dir):
+    """A HIP-graph replay of the eval forward is bit-identical to the eager launch sequence, on new input too."""
+    g = np.load(os.path.join(golden_dir, "g2_eval_forward_A.npz"))
+    m = build(320, 160, dev, golden_dir).eval()
+    w = torch.from_numpy(g["seg_wave"]).to(dev)
+    run = m.graphed_forward(w)
+    for x in (w, 0.5 * w.flip(-1).contiguous()):
+        ref = m(x).clone()
+        got = run(x).clone()
+        assert torch.equal(ref, got)
+    np.testing.assert_allclose(run(w).cpu().numpy(), g["seg_out"], atol=1e-4)
+    with pytest.raises(RuntimeError):
+        m.train().graphed_forward(w)
+
+
 def _keep(g, which, dev):
     shape = tuple(g["attn_keep_shape"])
     bits = np.unpackbits(g[which])[: int(np.prod(shape))].reshape(shape)
