@@ -40,6 +40,21 @@ int noise_istft_fwd(const float* logmag, const float* phase, const float* inv_ba
 int noise_istft_bwd(const float* d_wave, const float* wave_out, const float* logmag, const float* phase,
                     const float* inv_basisT, const float* window_sum, float* d_logmag, int accumulate,
                     int B, int T, int n_fft, int hop, void* stream);
+/* Symmetric-window variants of the three entry points above (same reference lines).  When the window
+ * satisfies w[n] = w[n_fft - n] (every scipy periodic window the reference can build, models.py:433-447) the
+ * Re rows of both bases are even and the Im rows odd about n_fft/2, so frames are folded
+ * (x[k] +- x[n_fft - k]) and only basis rows 0..n_fft/2 are multiplied: half the arithmetic, results equal up
+ * to summation order.  basisF / inv_basisF [n_fft/2 + 1][cols], cols = noise_stft_fold_cols(n_fft):
+ * column f = Re row f, column cols/2 + f = Im row f of the basis, taken at sample k.  noise_istft_fwd_sym reads
+ * the reference's inverse_basis buffer as is.  The caller checks the symmetry of its bases. */
+int noise_stft_fold_cols(int n_fft);
+int noise_stft_fwd_sym(const float* wave, const float* basisF, float* logmag, float* phase, float* absmax,
+                       int B, int L, int n_fft, int hop, void* stream);
+int noise_istft_fwd_sym(const float* logmag, const float* phase, const float* inv_basis, const float* window_sum,
+                        const float* vad_logit, float* wave_out, int B, int T, int n_fft, int hop, void* stream);
+int noise_istft_bwd_sym(const float* d_wave, const float* wave_out, const float* logmag, const float* phase,
+                        const float* inv_basisF, const float* window_sum, float* d_logmag, int accumulate,
+                        int B, int T, int n_fft, int hop, void* stream);
 
 /* ---- SNR mixer: process/audiolib.py:176-216 (+ :219-248, :30-35, :18-19), :251-289 ---------- */
 /* clean, noise [U][L] float64 (already length-matched); snr, level_draw [U]; outputs [U][L], level_out [U] */

@@ -47,6 +47,28 @@ def interleaved_transposed(basis, n_fft):
     return out.contiguous()
 
 
+def folded(basis, n_fft):
+    """(2F, n_fft) [Re rows ; Im rows] -> (n_fft/2 + 1, 2*FP): row k holds the basis at sample k, Re f in column
+    f and Im f in column FP + f (FP = F rounded up to 32).  Only valid for a symmetric basis (`is_symmetric`):
+    the kernel pairs sample k with n_fft - k."""
+    F = n_fft // 2 + 1
+    fp = ((F + 31) // 32) * 32
+    out = torch.zeros(F, 2 * fp, dtype=basis.dtype, device=basis.device)
+    out[:, :F] = basis[:F, :F].t()
+    out[:, fp:fp + F] = basis[F:, :F].t()
+    return out.contiguous()
+
+
+def is_symmetric(basis, n_fft, tol=1e-6):
+    """Re rows even, Im rows odd about n_fft/2 (to `tol` of the largest entry): true whenever the window obeys
+    w[n] = w[n_fft - n], as every periodic window of scipy.signal.get_window does."""
+    F = n_fft // 2 + 1
+    a = basis[:, 1:n_fft // 2]
+    m = basis[:, n_fft // 2 + 1:].flip(-1)
+    lim = tol * float(basis.abs().max())
+    return bool((a[:F] - m[:F]).abs().max() <= lim and (a[F:] + m[F:]).abs().max() <= lim)
+
+
 class _InverseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_magnitude, phase, stft):
@@ -93,31 +115,44 @@ class STFT(torch.nn.Module):
         self.register_buffer("forward_basis", forward_basis[:, None, :].contiguous())
         self.register_buffer("inverse_basis", inverse_basis[:, None, :].contiguous())
         self.register_buffer("window_sum", window_sum)
-        self._derived = None  # (key, forward basisT, inverse basisT) rebuilt when buffers move/change
+        self._derived = None  # (key, symmetric, forward layout, inverse layout) rebuilt when buffers move/change
+        self.use_symmetry = True  # False forces the general kernels (any basis)
 
     # -- kernel-side layouts of the two bases, derived lazily from the registered buffers
     def _bases(self):
+        """(symmetric, forward general, inverse general, forward folded, inverse folded); the folded layouts are
+        None when either basis lacks the mirror symmetry (or `use_symmetry` is off)."""
         fb, ib = self.forward_basis, self.inverse_basis
-        key = (fb.data_ptr(), fb._version, ib.data_ptr(), ib._version)
+        key = (fb.data_ptr(), fb._version, ib.data_ptr(), ib._version, self.use_symmetry)
         if self._derived is None or self._derived[0] != key:
-            self._derived = (key, interleaved_transposed(fb[:, 0, :], self.n_fft),
-                             interleaved_transposed(ib[:, 0, :], self.n_fft))
-        return self._derived[1], self._derived[2]
+            f2, i2 = fb[:, 0, :], ib[:, 0, :]
+            sym = self.use_symmetry and is_symmetric(f2, self.n_fft) and is_symmetric(i2, self.n_fft)
+            self._derived = (key, sym, interleaved_transposed(f2, self.n_fft), interleaved_transposed(i2, self.n_fft),
+                             folded(f2, self.n_fft) if sym else None, folded(i2, self.n_fft) if sym else None)
+        return self._derived[1:]
 
     def num_frames(self, L):
         return L // self.hop_length + 1
 
-    def forward(self, waveform, return_absmax=False):
+    def forward(self, waveform, return_absmax=False, reference_order=False):
+        """`reference_order=True` takes the general kernel, which accumulates every bin over the n_fft samples in
+        the order of the reference's conv1d, even when the folded one is available.  The two agree to fp32
+        rounding (the folded one is slightly closer to a float64 evaluation), but on bins near the 1e-3 magnitude
+        floor that rounding is ~5e-5 of the log-magnitude, and the per-clip normaliser max|log-magnitude| of the
+        denoiser (train/models.py:614-620) is usually attained there: the training step asks for the reference's
+        order on the network input so that its normaliser, and with it every gradient, reproduces the
+        reference's to ~1e-6 instead of ~1e-3."""
         _lib.require_cuda(waveform, self.forward_basis)
         B = waveform.shape[0]
         L = waveform.shape[-1]
         wave = waveform.reshape(B, L).contiguous().float()
         T = self.num_frames(L)
-        basisT, _ = self._bases()
+        sym, basisT, _, basisF, _ = self._bases()
+        sym = sym and not reference_order
         logmag = torch.empty(B, 1, self.cutoff, T, device=wave.device, dtype=torch.float32)
         phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32)
         absmax = torch.empty(B, device=wave.device, dtype=torch.float32) if return_absmax else None
-        _lib.call("noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisT), _lib.ptr(logmag), _lib.ptr(phase),
+        _lib.call("noise_stft_fwd_sym" if sym else "noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisF if sym else basisT), _lib.ptr(logmag), _lib.ptr(phase),
                   _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream(),
                   nbytes=4 * B * L + 8 * B * self.cutoff * T)
         if return_absmax:
@@ -132,19 +167,19 @@ class STFT(torch.nn.Module):
         n_out = self.hop_length * (T - 1)
         assert self.n_fft + self.hop_length * (T - 1) <= self.window_sum.numel(), "more frames than max_frames"
         out = torch.empty(B, 1, 1, n_out, device=lm.device, dtype=torch.float32)
-        _lib.call("noise_istft_fwd", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(self.inverse_basis),
+        _lib.call("noise_istft_fwd_sym" if self._bases()[0] else "noise_istft_fwd", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(self.inverse_basis),
                   _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft,
                   self.hop_length, _lib.stream(), nbytes=8 * B * F * T + 4 * B * n_out)
         return out
 
     def _inverse_bwd(self, grad_out, out, log_magnitude, phase, d_lm=None, accumulate=False):
         B, _, F, T = log_magnitude.shape
-        _, inv_basisT = self._bases()
+        sym, _, inv_basisT, _, inv_basisF = self._bases()
         g = grad_out.contiguous().float()
         if d_lm is None:
             d_lm = torch.empty_like(log_magnitude, dtype=torch.float32)
-        _lib.call("noise_istft_bwd", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
-                  _lib.ptr(phase.contiguous()), _lib.ptr(inv_basisT), _lib.ptr(self.window_sum), _lib.ptr(d_lm),
+        _lib.call("noise_istft_bwd_sym" if sym else "noise_istft_bwd", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
+                  _lib.ptr(phase.contiguous()), _lib.ptr(inv_basisF if sym else inv_basisT), _lib.ptr(self.window_sum), _lib.ptr(d_lm),
                   int(accumulate), B, T, self.n_fft, self.hop_length, _lib.stream(),
                   nbytes=8 * g.numel() + (12 + 4 * int(accumulate)) * B * F * T)
         return d_lm

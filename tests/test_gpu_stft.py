@@ -18,15 +18,23 @@ def dev():
 CONFIGS = [("A", 320, 160), ("B", 512, 128)]
 
 
-def _stft(n_fft, hop, dev, max_frames=1500):
+def _stft(n_fft, hop, dev, max_frames=1500, sym=True, window="hann", win_length=None):
+    """sym=True: the folded kernels (taken for every symmetric window); sym=False forces the general kernels."""
     from noise_amd import STFT
-    return STFT(max_frames, n_fft, hop, n_fft, "hann").to(dev)
+    st = STFT(max_frames, n_fft, hop, win_length or n_fft, window).to(dev)
+    st.use_symmetry = sym
+    assert st._bases()[0] == sym
+    return st
 
 
+SYM = pytest.mark.parametrize("sym", [True, False], ids=["folded", "general"])
+
+
+@SYM
 @pytest.mark.parametrize("tag,n_fft,hop", CONFIGS)
-def test_stft_golden(dev, golden_dir, tag, n_fft, hop):
+def test_stft_golden(dev, golden_dir, tag, n_fft, hop, sym):
     g = np.load(os.path.join(golden_dir, "g1_stft.npz"))
-    st = _stft(n_fft, hop, dev)
+    st = _stft(n_fft, hop, dev, sym=sym)
     for s in ("seg", "long"):
         w = torch.from_numpy(g[f"{tag}_{s}_wave"]).to(dev)
         lm, ph, amax = st.forward(w, return_absmax=True)
@@ -42,10 +50,11 @@ def test_stft_golden(dev, golden_dir, tag, n_fft, hop):
 
 
 @pytest.mark.parametrize("tag,n_fft,hop", CONFIGS)
+@SYM
 @pytest.mark.parametrize("B,L", [(1, 8000), (3, 16000), (2, 160000), (5, 1600), (2, 12345 // 1 * 1)])
-def test_stft_vs_oracle_and_roundtrip(dev, tag, n_fft, hop, B, L):
+def test_stft_vs_oracle_and_roundtrip(dev, tag, n_fft, hop, B, L, sym):
     from oracle import spectral as osp
-    st = _stft(n_fft, hop, dev)
+    st = _stft(n_fft, hop, dev, sym=sym)
     g = torch.Generator().manual_seed(L + B)
     w = (torch.randn(B, 1, 1, L, generator=g) * 0.1).clamp(-1, 1)
     fwd, inv, wsum = osp.stft_buffers(1500, n_fft, hop)
@@ -66,10 +75,11 @@ def test_stft_vs_oracle_and_roundtrip(dev, tag, n_fft, hop, B, L):
     np.testing.assert_allclose(rec.numpy()[..., : n - n_fft], w.numpy()[..., : n - n_fft], atol=1e-5)
 
 
-def test_istft_backward_matches_autograd(dev):
+@SYM
+def test_istft_backward_matches_autograd(dev, sym):
     from oracle import spectral as osp
     for tag, n_fft, hop in CONFIGS:
-        st = _stft(n_fft, hop, dev)
+        st = _stft(n_fft, hop, dev, sym=sym)
         fwd, inv, wsum = osp.stft_buffers(1500, n_fft, hop)
         g = torch.Generator().manual_seed(5)
         w = (torch.randn(3, 1, 1, 16 * hop * 5, generator=g) * 0.4).clamp(-1, 1)
@@ -84,6 +94,45 @@ def test_istft_backward_matches_autograd(dev):
         (out_d * gout.to(dev)).sum().backward()
         ref = lm.grad.numpy()
         np.testing.assert_allclose(lm_d.grad.cpu().numpy(), ref, atol=1e-5 * np.abs(ref).max() + 1e-6)
+
+
+@pytest.mark.parametrize("n_fft,hop,win,window", [(320, 160, 200, "hann"), (320, 160, 320, "hamming"), (1024, 256, 1024, "hann"),
+                                                 (64, 32, 64, "blackman"), (480, 160, 480, "hann")])
+def test_folded_equals_general(dev, n_fft, hop, win, window):
+    """Other windows, short windows padded to n_fft, the largest and smallest n_fft, n_fft/hop = 3: the folded
+    kernels agree with the general ones (same arithmetic up to summation order) in all three directions."""
+    a = _stft(n_fft, hop, dev, max_frames=200, sym=True, window=window, win_length=win)
+    b = _stft(n_fft, hop, dev, max_frames=200, sym=False, window=window, win_length=win)
+    g = torch.Generator().manual_seed(n_fft)
+    w = (torch.randn(3, 1, 1, 37 * hop + 11, generator=g) * 0.3).clamp(-1, 1).to(dev)
+    la, pa, ma = a.forward(w, return_absmax=True)
+    lb, pb, mb = b.forward(w, return_absmax=True)
+    Xa = torch.exp(la[:, 0].double()) * torch.exp(1j * pa.double())
+    Xb = torch.exp(lb[:, 0].double()) * torch.exp(1j * pb.double())
+    live = lb[:, 0] > np.log(1e-3) + 1e-6
+    assert (Xa - Xb).abs()[live].max().item() <= 1e-5 * Xb.abs().max().item()
+    np.testing.assert_allclose(ma.cpu().numpy(), mb.cpu().numpy(), rtol=1e-5)
+    lm = (lb + 0.2 * torch.randn(lb.shape, generator=g).to(dev))
+    outs, grads = [], []
+    gout = torch.randn(3, 1, 1, hop * (lb.shape[-1] - 1), generator=g).to(dev)
+    for st in (a, b):
+        x = lm.clone().requires_grad_(True)
+        o = st.inverse(x, pb)
+        (o * gout).sum().backward()
+        outs.append(o.detach().cpu().numpy())
+        grads.append(x.grad.cpu().numpy())
+    np.testing.assert_allclose(outs[0], outs[1], atol=1e-5)
+    np.testing.assert_allclose(grads[0], grads[1], atol=1e-5 * np.abs(grads[1]).max() + 1e-6)
+
+
+def test_asymmetric_basis_takes_general_kernels(dev):
+    from noise_amd import STFT
+    st = _stft(320, 160, dev, max_frames=100)
+    with torch.no_grad():
+        st.forward_basis[3, 0, 17] += 0.01
+    assert st._bases()[0] is False
+    # a periodic Hamming window shorter than n_fft: its first sample (0.08) has no mirror partner after centring
+    assert STFT(100, 320, 160, 200, "hamming").to(dev)._bases()[0] is False
 
 
 def test_stft_rejects_bad_arguments(dev):
