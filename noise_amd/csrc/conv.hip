@@ -573,15 +573,31 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
     else                                                                                                            \
       hipLaunchKernelGGL((__VA_ARGS__ false, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
   } while (0)
+#define LAUNCH_BWD_RECOMP()                                                                                          \
+  do {                                                                                                              \
+    if (hb && hg)                                                                                                   \
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, true, true, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);   \
+    else if (hb)                                                                                                    \
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, true, false, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+    else if (hg)                                                                                                    \
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, false, true, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+    else                                                                                                            \
+      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, false, false, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
+  } while (0)
+    // NOISE_DW_NO_RECOMPUTE (diagnostic): read the transposed layers' raw output back instead of recomputing it
+    static const bool recompute_off = getenv("NOISE_DW_NO_RECOMPUTE") != nullptr;
     if (cell)
       LAUNCH_BWD(walk_cell_bwd_kernel<);
     else if (!transposed)
       LAUNCH_BWD(walk_gather_bwd_kernel<1, true,);
     else if (sy == 1)
       LAUNCH_BWD(walk_gather_bwd_kernel<1, false,);
+    else if (G.coef3 != nullptr && !recompute_off)
+      LAUNCH_BWD_RECOMP();
     else
       LAUNCH_BWD(walk_gather_bwd_kernel<2, false,);
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD_RECOMP
   } else {
     grid = conv_grid((long)B * Hi * Wi, C);
     // the adjoint of a CONV gather is a CONVT gather and vice versa

@@ -225,7 +225,12 @@ __device__ __forceinline__ float4 bwd_activation(const BwdPixel& p, size_t off, 
   return av;
 }
 
-template <int S, bool FLIP, bool HAS_B, bool HAS_GO>
+// RECOMP (stride-2 transposed layers with a BatchNorm behind them): the raw layer output y that the lazy gradient
+// needs (dy = s*(dz - k1) + a2*(y - mean)) is recomputed from the layer input, which is four times smaller and walked
+// anyway, instead of being read back: y(2i-1+r, 2j-1+c) = sum a(i, j) * wk[3r+c] is the adjoint of the gather below.
+// The thread keeps the activated input rows oy and oy+1 at columns ox-1..ox+1; the centre of row oy doubles as the
+// destination pixel's activation.
+template <int S, bool FLIP, bool HAS_B, bool HAS_GO, bool RECOMP = false>
 __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
                                                               const float* __restrict__ w, float* __restrict__ g_in,
                                                               float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
@@ -265,7 +270,10 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
       // Software pipeline: everything the NEXT step needs from memory (S source rows of dz / y, the destination
       // pixel's activation and second gradient) is requested before the arithmetic of the current step, so a
       // thread always has one step of loads in flight.
-      float4 rz[S][3], ry[S][3], ray, rby, rgo;
+      float4 rz[S][3], ry[RECOMP ? 1 : S][3], ray, rby, rgo;
+      float4 rna[RECOMP ? 3 : 1], rnb[(RECOMP && HAS_B) ? 3 : 1];   // RECOMP: raw input row oy+1 at columns ox-1..ox+1
+      const bool vxm = ox > 0, vxp = ox + 1 < d.Wd;
+      const size_t nxm = (size_t)(vxm ? ox - 1 : ox) * C, nx = (size_t)ox * C, nxp = (size_t)(vxp ? ox + 1 : ox) * C;
       auto issue = [&](int oy, size_t off) {
 #pragma unroll
         for (int u = 0; u < S; ++u) {
@@ -274,14 +282,44 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
           rz[u][0] = ld4(gr.dz + row + (size_t)cx0 * C);
           rz[u][1] = ld4(gr.dz + row + (size_t)cx1 * C);
           rz[u][2] = ld4(gr.dz + row + (size_t)cx2 * C);
-          ry[u][0] = ld4(gr.y + row + (size_t)cx0 * C);
-          ry[u][1] = ld4(gr.y + row + (size_t)cx1 * C);
-          ry[u][2] = ld4(gr.y + row + (size_t)cx2 * C);
+          if (!RECOMP) {
+            ry[u][0] = ld4(gr.y + row + (size_t)cx0 * C);
+            ry[u][1] = ld4(gr.y + row + (size_t)cx1 * C);
+            ry[u][2] = ld4(gr.y + row + (size_t)cx2 * C);
+          }
         }
-        ray = ld4(px.a.y + off);
-        rby = HAS_B ? ld4(px.b.y + off) : f4(0.f);
+        if (RECOMP) {
+          const size_t nrow = ((size_t)bi * d.Hd + (oy + 1 < d.Hd ? oy + 1 : oy)) * d.Wd * C + c;
+          rna[0] = ld4(px.a.y + nrow + nxm);
+          rna[1] = ld4(px.a.y + nrow + nx);
+          rna[2] = ld4(px.a.y + nrow + nxp);
+          if (HAS_B) {
+            rnb[0] = ld4(px.b.y + nrow + nxm);
+            rnb[1] = ld4(px.b.y + nrow + nx);
+            rnb[2] = ld4(px.b.y + nrow + nxp);
+          }
+        } else {
+          ray = ld4(px.a.y + off);
+          rby = HAS_B ? ld4(px.b.y + off) : f4(0.f);
+        }
         rgo = HAS_GO ? ld4(px.epi.g_other + off) : f4(0.f);
       };
+      float4 a0[RECOMP ? 3 : 1], a1[RECOMP ? 3 : 1], ymid = f4(0.f);   // activated input rows oy, oy+1; raw centre of row oy
+      if (RECOMP) {
+        const size_t row = ((size_t)bi * d.Hd + r0) * d.Wd * C + c;
+        const float4 q0 = ld4(px.a.y + row + nxm), q1 = ld4(px.a.y + row + nx), q2 = ld4(px.a.y + row + nxp);
+        a0[0] = lazy4_act(px.a, q0);
+        a0[1] = lazy4_act(px.a, q1);
+        a0[2] = lazy4_act(px.a, q2);
+        if (HAS_B) {
+          a0[0] = a0[0] + lazy4_at(px.b, row + nxm);
+          a0[1] = a0[1] + lazy4_at(px.b, row + nx);
+          a0[2] = a0[2] + lazy4_at(px.b, row + nxp);
+        }
+        a0[0] = keep4(vxm, a0[0]);
+        a0[2] = keep4(vxp, a0[2]);
+        ymid = q1;
+      }
       issue(r0, ioff);
 #pragma unroll 1
       for (int oy = r0; oy < r1; ++oy, ioff += drow) {
@@ -294,10 +332,34 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
           t2[2] = keep4(vy && v2, t2[2]);
         } else {
           const bool vy2 = 2 * oy + 1 < d.Hs;   // row 2*oy always exists
+          if (RECOMP) {
+            const bool vn = oy + 1 < d.Hd;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            t1[j] = lazygrad4_eval(gr, rz[0][j], ry[0][j]);
-            t2[j] = lazygrad4_eval(gr, rz[S - 1][j], ry[S - 1][j]);
+            for (int j = 0; j < 3; ++j) {
+              a1[j] = lazy4_act(px.a, rna[j]);
+              if (HAS_B) a1[j] = a1[j] + lazy4_act(px.b, rnb[j]);
+            }
+            a1[0] = keep4(vn && vxm, a1[0]);
+            a1[1] = keep4(vn, a1[1]);
+            a1[2] = keep4(vn && vxp, a1[2]);
+            float4 y0[3], y1[3];
+            y0[0] = fma4(a0[0], wk[5], a0[1] * wk[3]);
+            y0[1] = a0[1] * wk[4];
+            y0[2] = fma4(a0[2], wk[3], a0[1] * wk[5]);
+            y1[0] = fma4(a1[1], wk[0], fma4(a1[0], wk[2], fma4(a0[1], wk[6], a0[0] * wk[8])));
+            y1[1] = fma4(a1[1], wk[1], a0[1] * wk[7]);
+            y1[2] = fma4(a1[2], wk[0], fma4(a1[1], wk[2], fma4(a0[2], wk[6], a0[1] * wk[8])));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              t1[j] = lazygrad4_eval(gr, rz[0][j], y0[j]);
+              t2[j] = lazygrad4_eval(gr, rz[S - 1][j], y1[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              t1[j] = lazygrad4_eval(gr, rz[0][j], ry[0][j]);
+              t2[j] = lazygrad4_eval(gr, rz[S - 1][j], ry[RECOMP ? 0 : S - 1][j]);
+            }
           }
           t1[0] = keep4(v0, t1[0]);
           t1[1] = keep4(v1, t1[1]);
@@ -306,9 +368,17 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
           t2[1] = keep4(vy2 && v1, t2[1]);
           t2[2] = keep4(vy2 && v2, t2[2]);
         }
-        const float4 yraw = ray;
-        float4 av = lazy4_act(px.a, yraw);
-        if (HAS_B) av = av + lazy4_act(px.b, rby);
+        const float4 yraw = RECOMP ? ymid : ray;
+        float4 av;
+        if (RECOMP) {
+          av = a0[1];
+          ymid = rna[1];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a0[j] = a1[j];
+        } else {
+          av = lazy4_act(px.a, yraw);
+          if (HAS_B) av = av + lazy4_act(px.b, rby);
+        }
         const float4 go = rgo;
         issue(oy + 1 < r1 ? oy + 1 : oy, oy + 1 < r1 ? ioff + drow : ioff);   // next step (a harmless repeat at the end)
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic below
