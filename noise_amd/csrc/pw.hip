@@ -277,7 +277,10 @@ constexpr int pw_bwd_min_blocks(int KC, int MTI) {
   return b > cap ? cap : (b < 1 ? 1 : b);
 }
 
-template <int KC, int MTI>
+// rows of the 64-pixel tile a thread stages when a row has `tiles` 16-channel tiles (see the staging map below)
+constexpr int pw_bwd_passes(int tiles) { return (WG_TILE + 256 / (tiles * 4) - 1) / (256 / (tiles * 4)); }
+
+template <int KC, int MTI, bool HAS_B>
 __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bs, const float* __restrict__ W,
                                                      float* __restrict__ g_in, BwdEpilogue E, float* __restrict__ dw_slab,
                                                      long npix, int N, int K) {
@@ -325,8 +328,8 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
 
   // Staging map: a thread keeps one group of 4 channels for every row it stages (rows rn, rn + RN, ... of the
   // 64-pixel tile), so the per-channel coefficients of the lazy transforms are loaded once, into registers.
-  constexpr int CGN = NP / 4, RN = 256 / CGN, PASS_N = (WG_TILE + RN - 1) / RN;
-  constexpr int CGK = KP / 4, RK = 256 / CGK, PASS_K = (WG_TILE + RK - 1) / RK;
+  constexpr int CGN = NP / 4, RN = 256 / CGN, PASS_N = pw_bwd_passes(KC);
+  constexpr int CGK = KP / 4, RK = 256 / CGK, PASS_K = pw_bwd_passes(MTI);
   const int rn = tid / CGN, cn = (tid - rn * CGN) * 4;
   const int rk = tid / CGK, ck = (tid - rk * CGK) * 4;
   const bool on = rn < RN && cn < N, ok = rk < RK && ck < K;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     asc = ld4(A.coef + ck);
     ash = ld4(A.coef + K + ck);
   }
-  if (ok && Bs.y && Bs.coef) {
+  if (HAS_B && ok && Bs.coef) {
     bsc = ld4(Bs.coef + ck);
     bsh = ld4(Bs.coef + K + ck);
   }
@@ -359,8 +362,58 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     const long pix0 = tile * WG_TILE;
     const long left = tile < ntiles ? npix - pix0 : 0;   // valid rows of this tile
     __syncthreads();
-    // loads are issued in batches of up to 4 rows per thread from clamped (always valid) addresses, then
-    // transformed and stored: the memory latency is paid once per batch, not once per row
+    // Every load is issued from a clamped (always valid) address, then transformed and stored.  When a thread's share
+    // of the tile is small enough to sit in registers (ONE_ROUND) all of it is requested before the first use, so a
+    // tile costs one memory round trip; otherwise in batches of up to 4 rows.
+    constexpr bool ONE_ROUND = 2 * PASS_N + (HAS_B ? 2 : 1) * PASS_K <= 12;
+    if (ONE_ROUND) {
+      float4 rz[PASS_N], ry[PASS_N], ra[PASS_K], rb[HAS_B ? PASS_K : 1];
+      const int cnc = on ? cn : 0, ckc = ok ? ck : 0;
+      const int rnc = rn < RN ? rn : 0, rkc = rk < RK ? rk : 0;
+#pragma unroll
+      for (int u = 0; u < PASS_N; ++u) {
+        long pix = pix0 + rnc + u * RN;
+        pix = pix < npix ? pix : npix - 1;
+        const size_t off = (size_t)pix * N + cnc;
+        rz[u] = ld4(G.dz + off);
+        ry[u] = G.coef3 ? ld4(G.y + off) : f4(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < PASS_K; ++u) {
+        long pix = pix0 + rkc + u * RK;
+        pix = pix < npix ? pix : npix - 1;
+        const size_t off = (size_t)pix * K + ckc;
+        ra[u] = ld4(A.y + off);
+        if (HAS_B) rb[u] = ld4(Bs.y + off);
+      }
+      if (rn < RN) {
+#pragma unroll
+        for (int u = 0; u < PASS_N; ++u) {
+          const int pp = rn + u * RN;
+          if (pp < WG_TILE) {
+            float4 v = rz[u];
+            if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
+            st4(dys + pp * pn + cn, (on && pp < left) ? v : f4(0.f));
+          }
+        }
+      }
+      if (rk < RK) {
+#pragma unroll
+        for (int u = 0; u < PASS_K; ++u) {
+          const int pp = rk + u * RK;
+          if (pp < WG_TILE) {
+            float4 v = fma4(ra[u], asc, ash);
+            if (A.relu6) v = relu6_4(v);
+            if (HAS_B) {
+              float4 w2 = fma4(rb[u], bsc, bsh);
+              if (Bs.relu6) w2 = relu6_4(w2);
+              v = v + w2;
+            }
+            st4(as + pp * pk + ck, (ok && pp < left) ? v : f4(0.f));
+          }
+        }
+      }
+    } else {
     if (rn < RN) {
       const int cnc = on ? cn : 0;
 #pragma unroll
@@ -417,6 +470,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
           }
         }
       }
+    }
     }
     __syncthreads();
     // ---- dgrad for this wave's 16 pixels
@@ -680,9 +734,15 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
 #define X(nt, mt)                                                                                                       \
   if constexpr (mt * nt <= 48) {                                                                                        \
     if (!done && KC == mt && MTI == nt) {                                                                               \
-      NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt>), smem);                                                                   \
-      hipLaunchKernelGGL((pw_bwd_kernel<mt, nt>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E, scratch, npix, \
-                         Cout, Cin);                                                                                    \
+      if (b_y != nullptr) {                                                                                             \
+        NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, true>), smem);                                                           \
+        hipLaunchKernelGGL((pw_bwd_kernel<mt, nt, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E,        \
+                           scratch, npix, Cout, Cin);                                                                   \
+      } else {                                                                                                          \
+        NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, false>), smem);                                                          \
+        hipLaunchKernelGGL((pw_bwd_kernel<mt, nt, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E,       \
+                           scratch, npix, Cout, Cin);                                                                   \
+      }                                                                                                                 \
       done = true;                                                                                                      \
     }                                                                                                                   \
   }
