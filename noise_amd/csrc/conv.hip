@@ -472,6 +472,9 @@ int check_c(const char* who, int C) {
 }  // namespace
 
 NOISE_EXPORT int noise_conv_max_blocks(void) { return 2048; }
+// The backward walkers hold one workgroup per CU (register-resident windows, coefficients and weight-gradient taps), so
+// more than 4 workgroups per CU only lengthens the slabs the finalize kernels fold.
+constexpr int BWD_MAX_BLOCKS = 1024;
 
 // transposed = 0: Conv2d, 1: ConvTranspose2d (both k3, p1, groups=C, no bias)
 NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y,
@@ -560,7 +563,7 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
     WalkDims wd{B, d.Ho, d.Wo, Hi, Wi, C, 0, 0, 0, 0};
     const bool cell = !transposed && sy == 2;
     wd.wown = cell ? d.Wo : Wi;
-    walk_plan(wd, cell ? d.Ho : Hi, noise_conv_max_blocks(), grid);
+    walk_plan(wd, cell ? d.Ho : Hi, BWD_MAX_BLOCKS, grid);
     const bool hb = b_y != nullptr, hg = g_other != nullptr;
 #define LAUNCH_BWD(...)                                                                                             \
   do {                                                                                                              \
@@ -654,7 +657,7 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
   hipStream_t st = (hipStream_t)stream;
   if (sy == 2 && sx == 2) {
     FirstWalkDims wd{B, H, W, hp, wp, d.Ho, d.Wo, C, pad_value, 0, 0, 0};
-    first_walk_plan(wd, noise_conv_max_blocks(), grid);
+    first_walk_plan(wd, BWD_MAX_BLOCKS, grid);
     const int CG = C / 4;
     if (CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64)
       hipLaunchKernelGGL(first_walk_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G,
@@ -727,7 +730,7 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
   BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
   if (sy == 2 && sx == 2) {
     LastWalkDims wd{B, Hi, Wi, C, H, W, Hfull - H, Wfull - W, 0, 0, 0, 0, 0, 0};
-    last_walk_plan(wd, false, noise_conv_max_blocks(), grid);
+    last_walk_plan(wd, false, BWD_MAX_BLOCKS, grid);
     const size_t sm = (size_t)PPB * 12 * C * sizeof(float);
     const bool hb = b_y != nullptr, hg = g_other != nullptr;
     const int CG = C / 4;
