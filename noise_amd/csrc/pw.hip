@@ -35,13 +35,27 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(LazySrc A, LazySrc Bs, Laz
   float* wfrag = lds;                    // [MT][KC][64][4]
   float* cf = lds + MT * KC * 256;       // [4][KC*16] (forward) or [6][KC*16] (gradient)
   constexpr int KP = KC * 16;
-  for (int idx = tid; idx < MT * KC * 256; idx += 256) {
-    const int r = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
-    const int jj = t % KC, m = t / KC;
-    const int co = 16 * m + (l & 15), ci = 16 * jj + 4 * (l >> 4) + r;
-    float v = 0.f;
-    if (co < N && ci < K) v = d.transW ? W[(size_t)ci * N + co] : W[(size_t)co * K + ci];
-    wfrag[idx] = v;
+  if (d.transW) {
+    for (int idx = tid; idx < MT * KC * 256; idx += 256) {
+      const int r = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+      const int jj = t % KC, m = t / KC;
+      const int co = 16 * m + (l & 15), ci = 16 * jj + 4 * (l >> 4) + r;
+      wfrag[idx] = (co < N && ci < K) ? W[(size_t)ci * N + co] : 0.f;
+    }
+  } else {
+    // W is read once, row by row, with coalesced 16-byte loads; four consecutive input channels of one output channel
+    // are one float4 of the fragment image ([m][jj][lane = co%16 + 16*((ci%16)/4)][ci%4])
+    if ((N & 15) || (K & 15)) {
+      for (int idx = tid; idx < MT * KC * 256; idx += 256) wfrag[idx] = 0.f;
+      __syncthreads();
+    }
+    const int K4 = K >> 2;
+#pragma unroll 4
+    for (int e = tid; e < N * K4; e += 256) {
+      const int co = e / K4, ci = 4 * (e - co * K4);
+      const float4 v = ld4(W + (size_t)co * K + ci);
+      st4(wfrag + ((((co >> 4) * KC + (ci >> 4)) * 64) + (co & 15) + 16 * ((ci & 15) >> 2)) * 4, v);
+    }
   }
   for (int k = tid; k < KP; k += 256) {
     const bool in = k < K;
@@ -293,11 +307,24 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
   float* dys = wfrag + MTI * KC * 256;           // [64][pn]
   float* as = dys + WG_TILE * pn;                // [64][pk]
   float* ecf = as + WG_TILE * pk;                // [5][KP] producer BN coefficients for the epilogue
-  for (int idx = tid; idx < MTI * KC * 256; idx += 256) {
-    const int r = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
-    const int jj = t % KC, m = t / KC;
-    const int ci = 16 * m + (l & 15), co = 16 * jj + 4 * (l >> 4) + r;
-    wfrag[idx] = (co < N && ci < K) ? W[(size_t)co * K + ci] : 0.f;
+  // W is read once, row by row, with coalesced 16-byte loads and scattered into the fragment image
+  // ([m][jj][lane = ci%16 + 16*((co%16)/4)][co%4])
+  if ((N & 15) || (K & 15)) {
+    for (int idx = tid; idx < MTI * KC * 256; idx += 256) wfrag[idx] = 0.f;
+    __syncthreads();
+  }
+  {
+    const int K4 = K >> 2;
+#pragma unroll 4
+    for (int e = tid; e < N * K4; e += 256) {
+      const int co = e / K4, ci = 4 * (e - co * K4);
+      const float4 v = ld4(W + (size_t)co * K + ci);
+      float* dst = wfrag + ((((ci >> 4) * KC + (co >> 4)) * 64) + (ci & 15) + 16 * ((co & 15) >> 2)) * 4 + (co & 3);
+      dst[0] = v.x;
+      dst[4] = v.y;
+      dst[8] = v.z;
+      dst[12] = v.w;
+    }
   }
   for (int k = tid; k < KP; k += 256) {
     const bool in = k < K && E.coef != nullptr;

@@ -243,23 +243,36 @@ __global__ __launch_bounds__(64 * STFT_SYM_MAX_WAVES) void stft_frames_sym_kerne
   const int nS = (STFT_TF - 1) * hop + n_fft;
   const int half = n_fft / 2;
 
-  for (int i = tid; i < nS; i += nthr) {
-    int s = t0 * hop + i - half;
-    float v;
-    if (MODE == 0) {
-      if (s < 0) s = -s;
-      if (s >= d.L) s = 2 * (d.L - 1) - s;
-      s = min(max(s, 0), d.L - 1);
-      v = sig[(size_t)b * d.L + s];
-    } else {
-      v = 0.f;
-      if (s >= 0 && s < d.Lout) {
-        size_t o = (size_t)b * d.Lout + s;
-        float w = wave_out[o];
-        v = (w > -1.f && w < 1.f) ? sig[o] * wsum[s + half] : 0.f;
+  // four samples per thread and trip: the loads of a trip are independent and issued together (clamped addresses,
+  // select afterwards), so staging costs nS / (4 * threads) memory round trips
+  for (int i0 = tid; i0 < nS; i0 += 4 * nthr) {
+    float v[4], w[4], e[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthr;
+      int s = t0 * hop + i - half;
+      if (MODE == 0) {
+        if (s < 0) s = -s;
+        if (s >= d.L) s = 2 * (d.L - 1) - s;
+        s = min(max(s, 0), d.L - 1);
+        v[u] = sig[(size_t)b * d.L + s];
+      } else {
+        in[u] = s >= 0 && s < d.Lout;
+        const int sc = in[u] ? s : 0;
+        const size_t o = (size_t)b * d.Lout + sc;
+        w[u] = wave_out[o];
+        v[u] = sig[o];
+        e[u] = wsum[sc + half];
       }
     }
-    lds[i + i / hop] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthr;
+      float x = v[u];
+      if (MODE != 0) x = (in[u] && w[u] > -1.f && w[u] < 1.f) ? x * e[u] : 0.f;
+      if (i < nS) lds[i + (int)__umulhi((unsigned)i, d.hop_magic)] = x;
+    }
   }
   __syncthreads();
 

@@ -53,6 +53,19 @@ elif which == "dw_bwd":
     ms = timed(lambda: ops.dw3x3_bwd((dz, y, coef(C, 6)), (a, coef(C, 5), True), None, w, g_in, dw, scratch, bool(tr), B, Hi,
                                      Wi, C, (s, s), None, (coef(C, 5), True)))
     nbytes = 4 * B * C * (2 * Ho * Wo + 2 * Hi * Wi)
+elif which == "stft":
+    n_fft, hop, B, L = args
+    from noise_amd import STFT
+    st = STFT(L // hop + 1, n_fft, hop, n_fft, "hann").to(dev)
+    x = torch.randn(B, 1, 1, L, device=dev) * 0.1
+    lm, ph = st.forward(x)
+    g = torch.randn(B, 1, 1, hop * (L // hop), device=dev)
+    out = st._inverse_raw(lm, ph, None)
+    ms = timed(lambda: st.forward(x, return_absmax=True))
+    ms_i = timed(lambda: st._inverse_raw(lm, ph, None))
+    ms_b = timed(lambda: st._inverse_bwd(g, out, lm, ph))
+    nbytes = 4 * B * L + 8 * lm.numel()
+    print(f"istft fwd {ms_i:.3f} ms, istft bwd {ms_b:.3f} ms")
 else:
     raise SystemExit("unknown kernel")
 print(f"{which} {args}: {ms:.3f} ms  {nbytes / 1e6 / ms:.1f} GB/s")
