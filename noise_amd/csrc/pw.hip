@@ -650,6 +650,19 @@ int dispatch_pw(int KC, int MT, LazySrc A, LazySrc Bs, LazyGrad G, const float* 
   return 1;
 }
 
+// A persistent grid larger than what the GPU holds at once runs in rounds, and a last round that is only partly
+// full costs as much as a full one: round the grid down to a whole number of rounds (CUs x workgroups per CU).
+int whole_rounds(int grid, int blocks_per_cu) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  const int round = cus * blocks_per_cu;
+  return grid > round ? (grid / round) * round : grid;
+}
+
 int pw_grid(long npix) { return noise_grid(npix, 16 * 4 * 4, 1024); }
 
 }  // namespace
@@ -751,8 +764,7 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
   LazyGrad G{dz, y_out, coef3};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   BwdEpilogue E{g_other, epi_coef, epi_relu6, epi_coef ? stats_slab : nullptr};
-  const int grid = noise_grid(npix, WG_TILE, noise_pw_bwd_max_rows(Cout, Cin));
-  if (slab_rows) *slab_rows = grid;
+  int grid = noise_grid(npix, WG_TILE, noise_pw_bwd_max_rows(Cout, Cin));
   size_t smem = (size_t)(MTI * KC * 256 + WG_TILE * (KC * 16 + 4) + WG_TILE * (MTI * 16 + 4) + 5 * MTI * 16) * sizeof(float);
   if ((size_t)Cout * Cin * sizeof(float) > smem) smem = (size_t)Cout * Cin * sizeof(float);
   NOISE_REQUIRE(smem <= 160 * 1024, "noise_pw_bwd: %dx%d layer needs %zu bytes of LDS", Cout, Cin, smem);
@@ -761,6 +773,7 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
 #define X(nt, mt)                                                                                                       \
   if constexpr (mt * nt <= 48) {                                                                                        \
     if (!done && KC == mt && MTI == nt) {                                                                               \
+      grid = whole_rounds(grid, pw_bwd_min_blocks(mt, nt));                                                             \
       if (b_y != nullptr) {                                                                                             \
         NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, true>), smem);                                                           \
         hipLaunchKernelGGL((pw_bwd_kernel<mt, nt, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E,        \
@@ -776,6 +789,7 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
   PW_CASES(X)
 #undef X
   NOISE_REQUIRE(done, "noise_pw_bwd: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
+  if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_pw_bwd");
   hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, SLAB_COLS)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
   NOISE_CHECK_LAUNCH("noise_pw_bwd/reduce");
