@@ -46,6 +46,33 @@ static inline int noise_grid(long work_items, int per_block, int cap = 2048) {
   return (int)g;
 }
 
+// A persistent grid larger than what the GPU holds at once runs in rounds, and a last round that is only partly full
+// costs as much as a full one: round the grid down to a whole number of rounds (CUs x resident workgroups per CU, as
+// the runtime reports them for this kernel, block size and dynamic LDS).
+static inline int noise_num_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus;
+}
+template <typename KernelT>
+static inline int noise_whole_rounds(int grid, KernelT kernel, int threads, size_t smem) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, smem) != hipSuccess || per_cu < 1) return grid;
+  const int round = noise_num_cus() * per_cu;
+  return grid > round ? grid / round * round : grid;
+}
+#define NOISE_LAUNCH_ROUNDS(kernel, grid, smem, st, ...)                               \
+  do {                                                                                 \
+    auto kfn_ = kernel;                                                                \
+    grid = noise_whole_rounds(grid, kfn_, 256, smem);                                  \
+    hipLaunchKernelGGL(kfn_, dim3(grid), dim3(256), smem, st, __VA_ARGS__);            \
+  } while (0)
+
 // ---- lazily normalised activations --------------------------------------------------------
 // A convolution writes its RAW output y; BatchNorm (+ReLU6) is applied by whoever reads it:
 //     a[p][c] = act(scale[c] * y[p][c] + shift[c])

@@ -500,14 +500,13 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
     const bool cell = transposed && sy == 2;
     wd.wown = cell ? Wi : d.Wo;
     walk_plan(wd, cell ? Hi : d.Ho, noise_conv_max_blocks(), grid);
-    if (slab_rows) *slab_rows = grid;
     const bool hb = b_y != nullptr;
 #define LAUNCH_FWD(...)                                                                                            \
   do {                                                                                                             \
     if (hb)                                                                                                        \
-      hipLaunchKernelGGL((__VA_ARGS__ true>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);          \
+      NOISE_LAUNCH_ROUNDS((__VA_ARGS__ true>), grid, smem, st, A, Bs, w, out, stats_slab, wd);          \
     else                                                                                                           \
-      hipLaunchKernelGGL((__VA_ARGS__ false>), dim3(grid), dim3(256), smem, st, A, Bs, w, out, stats_slab, wd);         \
+      NOISE_LAUNCH_ROUNDS((__VA_ARGS__ false>), grid, smem, st, A, Bs, w, out, stats_slab, wd);         \
   } while (0)
     if (cell)
       LAUNCH_FWD(walk_cell_fwd_kernel<);
@@ -518,6 +517,7 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
     else
       LAUNCH_FWD(walk_gather_fwd_kernel<2, false,);
 #undef LAUNCH_FWD
+    if (slab_rows) *slab_rows = grid;
     NOISE_CHECK_LAUNCH("noise_dw3x3_fwd");
     return 0;
   }
@@ -568,24 +568,24 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
 #define LAUNCH_BWD(...)                                                                                             \
   do {                                                                                                              \
     if (hb && hg)                                                                                                   \
-      hipLaunchKernelGGL((__VA_ARGS__ true, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);   \
+      NOISE_LAUNCH_ROUNDS((__VA_ARGS__ true, true>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd);   \
     else if (hb)                                                                                                    \
-      hipLaunchKernelGGL((__VA_ARGS__ true, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+      NOISE_LAUNCH_ROUNDS((__VA_ARGS__ true, false>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
     else if (hg)                                                                                                    \
-      hipLaunchKernelGGL((__VA_ARGS__ false, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+      NOISE_LAUNCH_ROUNDS((__VA_ARGS__ false, true>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
     else                                                                                                            \
-      hipLaunchKernelGGL((__VA_ARGS__ false, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
+      NOISE_LAUNCH_ROUNDS((__VA_ARGS__ false, false>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
   } while (0)
 #define LAUNCH_BWD_RECOMP()                                                                                          \
   do {                                                                                                              \
     if (hb && hg)                                                                                                   \
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, true, true, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);   \
+      NOISE_LAUNCH_ROUNDS((walk_gather_bwd_kernel<2, false, true, true, true>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd);   \
     else if (hb)                                                                                                    \
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, true, false, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+      NOISE_LAUNCH_ROUNDS((walk_gather_bwd_kernel<2, false, true, false, true>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
     else if (hg)                                                                                                    \
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, false, true, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
+      NOISE_LAUNCH_ROUNDS((walk_gather_bwd_kernel<2, false, false, true, true>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd);  \
     else                                                                                                            \
-      hipLaunchKernelGGL((walk_gather_bwd_kernel<2, false, false, false, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
+      NOISE_LAUNCH_ROUNDS((walk_gather_bwd_kernel<2, false, false, false, true>), grid, smem, st, G, A, Bs, w, g_in, scratch, E, wd); \
   } while (0)
     // NOISE_DW_NO_RECOMPUTE (diagnostic): read the transposed layers' raw output back instead of recomputing it
     static const bool recompute_off = getenv("NOISE_DW_NO_RECOMPUTE") != nullptr;
@@ -631,11 +631,11 @@ NOISE_EXPORT int noise_first_conv_fwd(const float* logmag, const float* absmax, 
     first_walk_plan(wd, noise_conv_max_blocks(), grid);
     const int CG = C / 4;
     if (CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64)
-      hipLaunchKernelGGL(first_walk_fwd_kernel<true>, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
-                         (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
+      NOISE_LAUNCH_ROUNDS(first_walk_fwd_kernel<true>, grid, (size_t)PPB * 2 * C * sizeof(float),
+                          (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
     else
-      hipLaunchKernelGGL(first_walk_fwd_kernel<false>, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
-                         (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
+      NOISE_LAUNCH_ROUNDS(first_walk_fwd_kernel<false>, grid, (size_t)PPB * 2 * C * sizeof(float),
+                          (hipStream_t)stream, logmag, absmax, w, out, stats_slab, wd);
   } else {
     hipLaunchKernelGGL(first_conv_fwd_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float),
                        (hipStream_t)stream, logmag, absmax, w, out, stats_slab, d);
@@ -660,10 +660,10 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
     first_walk_plan(wd, BWD_MAX_BLOCKS, grid);
     const int CG = C / 4;
     if (CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64)
-      hipLaunchKernelGGL(first_walk_wgrad_kernel<true>, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G,
+      NOISE_LAUNCH_ROUNDS(first_walk_wgrad_kernel<true>, grid, (size_t)PPB * 9 * C * sizeof(float), st, G,
                          logmag, absmax, scratch, wd);
     else
-      hipLaunchKernelGGL(first_walk_wgrad_kernel<false>, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G,
+      NOISE_LAUNCH_ROUNDS(first_walk_wgrad_kernel<false>, grid, (size_t)PPB * 9 * C * sizeof(float), st, G,
                          logmag, absmax, scratch, wd);
   } else {
     hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
@@ -693,10 +693,10 @@ NOISE_EXPORT int noise_last_convT_fwd(const float* a_y, const float* a_coef, int
     int grid;
     last_walk_plan(wd, true, 4096, grid);
     if (b_y != nullptr)
-      hipLaunchKernelGGL(last_cell_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
+      NOISE_LAUNCH_ROUNDS(last_cell_fwd_kernel<true>, grid, 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
                          absmax, enh, filt, wd);
     else
-      hipLaunchKernelGGL(last_cell_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
+      NOISE_LAUNCH_ROUNDS(last_cell_fwd_kernel<false>, grid, 0, (hipStream_t)stream, A, Bs, w, bias, logmag,
                          absmax, enh, filt, wd);
   } else if (CG <= 16 && (CG & (CG - 1)) == 0) {
     const int grid = noise_grid((long)B * H * W, 256 / CG, 8192);
@@ -738,10 +738,10 @@ NOISE_EXPORT int noise_last_convT_bwd(const float* d_enh, const float* enh, cons
 #define LAUNCH_LAST(HB, HG)                                                                                        \
   do {                                                                                                             \
     if (coop)                                                                                                      \
-      hipLaunchKernelGGL((last_gather_bwd_kernel<HB, HG, true>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, \
+      NOISE_LAUNCH_ROUNDS((last_gather_bwd_kernel<HB, HG, true>), grid, sm, st, d_enh, enh, absmax, A, \
                          Bs, w, g_in, scratch, E, wd);                                                             \
     else                                                                                                           \
-      hipLaunchKernelGGL((last_gather_bwd_kernel<HB, HG, false>), dim3(grid), dim3(256), sm, st, d_enh, enh, absmax, A, \
+      NOISE_LAUNCH_ROUNDS((last_gather_bwd_kernel<HB, HG, false>), grid, sm, st, d_enh, enh, absmax, A, \
                          Bs, w, g_in, scratch, E, wd);                                                             \
   } while (0)
     if (hb && hg) LAUNCH_LAST(true, true);

@@ -625,11 +625,11 @@ __global__ __launch_bounds__(256) void pw_slab_reduce_kernel(const float* __rest
 
 template <bool GRAD, int KC, int MT>
 void launch_pw(LazySrc A, LazySrc Bs, LazyGrad G, const float* W, const float* add, float* out, float* slab, PwDims d,
-               int grid, hipStream_t st) {
+               int& grid, hipStream_t st) {
   size_t smem = (size_t)(MT * KC * 256 + 6 * KC * 16) * sizeof(float);
   const size_t red = (size_t)8 * MT * 16 * sizeof(float);
   if (red > smem) smem = red;
-  hipLaunchKernelGGL((pw_gemm_kernel<GRAD, KC, MT>), dim3(grid), dim3(256), smem, st, A, Bs, G, W, add, out, slab, d);
+  NOISE_LAUNCH_ROUNDS((pw_gemm_kernel<GRAD, KC, MT>), grid, smem, st, A, Bs, G, W, add, out, slab, d);
 }
 
 #define PW_CASES(X)                                                                                     \
@@ -639,7 +639,7 @@ void launch_pw(LazySrc A, LazySrc Bs, LazyGrad G, const float* W, const float* a
 
 template <bool GRAD>
 int dispatch_pw(int KC, int MT, LazySrc A, LazySrc Bs, LazyGrad G, const float* W, const float* add, float* out,
-                float* slab, PwDims d, int grid, hipStream_t st) {
+                float* slab, PwDims d, int& grid, hipStream_t st) {
 #define X(kc, mt)                                                          \
   if (KC == kc && MT == mt) {                                              \
     launch_pw<GRAD, kc, mt>(A, Bs, G, W, add, out, slab, d, grid, st);     \
@@ -648,19 +648,6 @@ int dispatch_pw(int KC, int MT, LazySrc A, LazySrc Bs, LazyGrad G, const float* 
   PW_CASES(X)
 #undef X
   return 1;
-}
-
-// A persistent grid larger than what the GPU holds at once runs in rounds, and a last round that is only partly
-// full costs as much as a full one: round the grid down to a whole number of rounds (CUs x workgroups per CU).
-int whole_rounds(int grid, int blocks_per_cu) {
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n;
-  }();
-  const int round = cus * blocks_per_cu;
-  return grid > round ? (grid / round) * round : grid;
 }
 
 int pw_grid(long npix) { return noise_grid(npix, 16 * 4 * 4, 1024); }
@@ -678,10 +665,10 @@ NOISE_EXPORT int noise_pw_fwd(const float* a_y, const float* a_coef, int a_relu6
   PwDims d{npix, K, N, 0};
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   LazyGrad G{nullptr, nullptr, nullptr};
-  const int grid = pw_grid(npix);
-  if (slab_rows) *slab_rows = grid;
+  int grid = pw_grid(npix);
   NOISE_REQUIRE(dispatch_pw<false>(KC, MT, A, Bs, G, w, nullptr, out, stats_slab, d, grid, (hipStream_t)stream) == 0,
                 "noise_pw_fwd: no kernel instance for K=%d N=%d", K, N);
+  if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_pw_fwd");
   return 0;
 }
@@ -697,7 +684,8 @@ NOISE_EXPORT int noise_pw_dgrad(const float* dz, const float* y_out, const float
   PwDims d{npix, Cout, Cin, 1};
   LazySrc A{nullptr, nullptr, 0};
   LazyGrad G{dz, y_out, coef3};
-  NOISE_REQUIRE(dispatch_pw<true>(KC, MT, A, A, G, w, add, g_in, nullptr, d, pw_grid(npix), (hipStream_t)stream) == 0,
+  int grid = pw_grid(npix);
+  NOISE_REQUIRE(dispatch_pw<true>(KC, MT, A, A, G, w, add, g_in, nullptr, d, grid, (hipStream_t)stream) == 0,
                 "noise_pw_dgrad: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
   NOISE_CHECK_LAUNCH("noise_pw_dgrad");
   return 0;
@@ -773,15 +761,14 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
 #define X(nt, mt)                                                                                                       \
   if constexpr (mt * nt <= 48) {                                                                                        \
     if (!done && KC == mt && MTI == nt) {                                                                               \
-      grid = whole_rounds(grid, pw_bwd_min_blocks(mt, nt));                                                             \
       if (b_y != nullptr) {                                                                                             \
         NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, true>), smem);                                                           \
-        hipLaunchKernelGGL((pw_bwd_kernel<mt, nt, true>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E,        \
-                           scratch, npix, Cout, Cin);                                                                   \
+        NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, true>), grid, smem, st, G, A, Bs, w, g_in, E, scratch, npix, Cout,   \
+                            Cin);                                                                                       \
       } else {                                                                                                          \
         NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, false>), smem);                                                          \
-        hipLaunchKernelGGL((pw_bwd_kernel<mt, nt, false>), dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, E,       \
-                           scratch, npix, Cout, Cin);                                                                   \
+        NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, false>), grid, smem, st, G, A, Bs, w, g_in, E, scratch, npix, Cout,  \
+                            Cin);                                                                                       \
       }                                                                                                                 \
       done = true;                                                                                                      \
     }                                                                                                                   \
