@@ -7,6 +7,7 @@
 //   loss      = waveform + spectral + vad                                   (:790)
 // All reductions are per-workgroup partials folded by one finalize kernel (no atomics, reproducible).
 #include "common.h"
+#include "lazy.h"
 
 namespace {
 
@@ -187,6 +188,207 @@ __global__ __launch_bounds__(256) void wave_pair_sorted_kernel(const float* __re
   if (tid == 0) partial[blockIdx.x] = total;
 }
 
+// Same algorithm for 256 <= NP <= 2048, with the sort in registers.  A workgroup owns RT = 8 consecutive time samples:
+// the clean values of all B clips at those samples are staged once (32-byte pieces per clip, transposed into LDS rows),
+// and every thread reads and writes its own clips' 8 waveform samples / gradients as two float4.  Per time sample the
+// row is sorted with each thread holding EPT = NP/256 consecutive elements: compare-exchange partners at distance
+// j < EPT are the thread's own registers, j < 64*EPT another lane of the wave (shuffle), and only the 1-3 largest
+// distances go through LDS, so a 2048-element sort needs 6 barriers instead of 66.
+constexpr int RT = 4;
+
+template <int EPT>
+__device__ __forceinline__ void bitonic_sort_row(float (&v)[EPT], float* xch, int tid) {
+  constexpr int NP = 256 * EPT;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64 * EPT) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) xch[tid * EPT + e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int idx = tid * EPT + e;
+          const float o = xch[idx ^ j];
+          const bool up = (idx & k) == 0, lower = (idx & j) == 0;
+          v[e] = (lower == up) ? fminf(v[e], o) : fmaxf(v[e], o);
+        }
+      } else if (j >= EPT) {
+        const int lj = j / EPT;
+        const bool lower = (lane & lj) == 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const float o = __shfl_xor(v[e], lj, 64);
+          const bool up = ((tid * EPT + e) & k) == 0;
+          v[e] = (lower == up) ? fminf(v[e], o) : fmaxf(v[e], o);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          if ((e & j) == 0) {
+            const bool up = ((tid * EPT + e) & k) == 0;
+            const float a = v[e], b = v[e | j];
+            const float mn = fminf(a, b), mx = fmaxf(a, b);
+            v[e] = up ? mn : mx;
+            v[e | j] = up ? mx : mn;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPT>
+__global__ __launch_bounds__(256, 2) void wave_pair_rows_kernel(const float* __restrict__ w, const float* __restrict__ c,
+                                                             int B, int L, float scale, float* __restrict__ d_w,
+                                                             double* __restrict__ partial) {
+  constexpr int NP = 256 * EPT, R = EPT;   // R: clips per thread (B <= NP)
+  extern __shared__ double lds_d[];
+  double* P = lds_d;                                   // [B + 1] prefix sums of the sorted row
+  float* srt = reinterpret_cast<float*>(P + B + 1);    // [NP] sorted row (also the exchange buffer of the sort)
+  float* ct = srt + NP;                                // [RT][pitch] clean tile, row = time sample
+  __shared__ double red[4], wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pitch = B | 1;
+  const int t0 = blockIdx.x * RT;
+  const bool vec = (L & 3) == 0 && t0 + RT <= L;       // whole, 16-byte aligned pieces
+
+  constexpr int Q = RT / 4;   // float4 pieces per clip
+  for (int e = tid; e < Q * B; e += 256) {
+    const int j = e / Q, hf = e - j * Q;
+    float x[4];
+    if (vec) {
+      const float4 q = ld4(c + (size_t)j * L + t0 + 4 * hf);
+      x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + 4 * hf + u;
+        x[u] = t < L ? c[(size_t)j * L + t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ct[(4 * hf + u) * pitch + j] = x[u];
+  }
+  float wv[R][RT], dv[R][RT];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int u = 0; u < RT; ++u) dv[r][u] = 0.f;
+    const int i = tid + 256 * r;
+    const size_t row = (size_t)(i < B ? i : 0) * L + t0;
+    if (vec) {
+#pragma unroll
+      for (int h = 0; h < Q; ++h) {
+        const float4 q0 = ld4(w + row + 4 * h);
+        wv[r][4 * h] = q0.x; wv[r][4 * h + 1] = q0.y; wv[r][4 * h + 2] = q0.z; wv[r][4 * h + 3] = q0.w;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < RT; ++u) wv[r][u] = t0 + u < L ? w[row + u] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  double total = 0.0;
+  // the loop stays rolled (its body holds the whole unrolled sorting network); wv / dv are therefore addressed with
+  // compile-time indices and selects, never with tt
+#pragma unroll 1
+  for (int tt = 0; tt < RT; ++tt) {
+    float v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int j = tid * EPT + e;
+      v[e] = j < B ? ct[tt * pitch + j] : INFINITY;
+    }
+    bitonic_sort_row<EPT>(v, srt, tid);
+    // prefix sums in double: own elements, then a scan over the wave, then over the four waves
+    double run[EPT], own = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      own += tid * EPT + e < B ? (double)v[e] : 0.0;
+      run[e] = own;
+    }
+    double inc = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    __syncthreads();              // the sort's last exchange (if any) has been read
+    if (lane == 63) wtot[wave] = inc;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) srt[tid * EPT + e] = v[e];
+    __syncthreads();
+    double base = inc - own;
+    for (int wv2 = 0; wv2 < wave; ++wv2) base += wtot[wv2];
+    if (tid == 0) P[0] = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (tid * EPT + e < B) P[tid * EPT + e + 1] = base + run[e];
+    __syncthreads();
+    const bool live = t0 + tt < L;
+    // k = #{c < x} and k2 = #{c <= x} for the thread's R clips by branch-free binary searches over the padded row
+    // (entries >= B are +inf, so no bound check): the 2R searches advance in lock step, their LDS reads overlap
+    float x[R];
+    int k[R], k2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      x[r] = wv[r][0];
+#pragma unroll
+      for (int u = 1; u < RT; ++u) x[r] = u == tt ? wv[r][u] : x[r];
+      k[r] = k2[r] = 0;
+    }
+#pragma unroll
+    for (int s2 = NP >> 1; s2 > 0; s2 >>= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float a = srt[k[r] + s2 - 1], b = srt[k2[r] + s2 - 1];
+        k[r] += a < x[r] ? s2 : 0;
+        k2[r] += b <= x[r] ? s2 : 0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {   // the steps above reach NP - 1 at most: one more element decides a full row
+      k[r] += srt[k[r]] < x[r] ? 1 : 0;
+      k2[r] += srt[k2[r]] <= x[r] ? 1 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = tid + 256 * r;
+      const int ka = k[r] < B ? k[r] : B, kb = k2[r] < B ? k2[r] : B;   // x = +inf would count the padding
+      const double xd = (double)x[r];
+      if (live && i < B) total += xd * ka - P[ka] + (P[B] - P[kb]) - xd * (B - kb);
+      const float gv = (float)(ka - (B - kb)) * scale;
+#pragma unroll
+      for (int u = 0; u < RT; ++u) dv[r][u] = u == tt ? gv : dv[r][u];
+    }
+    __syncthreads();              // srt / P are rewritten for the next time sample
+  }
+  if (d_w != nullptr) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = tid + 256 * r;
+      if (i >= B) continue;
+      const size_t row = (size_t)i * L + t0;
+      if (vec) {
+#pragma unroll
+        for (int h = 0; h < Q; ++h)
+          st4(d_w + row + 4 * h, make_float4(dv[r][4 * h], dv[r][4 * h + 1], dv[r][4 * h + 2], dv[r][4 * h + 3]));
+      } else {
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+          if (t0 + u < L) d_w[row + u] = dv[r][u];
+      }
+    }
+  }
+  total = block_sum_d(total, red);
+  if (tid == 0) partial[blockIdx.x] = total;
+}
+
 // out[0..3] = loss, vad_loss, waveform_loss, spectral_loss;  d_vad[b] = (sigmoid(x) - y)/B
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ spec_partial, int n_spec,
                                                             double spec_count, const double* __restrict__ wave_partial,
@@ -264,6 +466,27 @@ NOISE_EXPORT int noise_wave_pair_l1(const float* wave, const float* clean, float
   if (B >= 64 && B <= 2048) {   // sorted algorithm: B log B instead of B^2 per time sample
     int NP = 64;
     while (NP < B) NP <<= 1;
+    if (NP >= 256) {            // register sort, 8 time samples per workgroup
+      const int pitch = B | 1;
+      const size_t smem = (size_t)(B + 1) * sizeof(double) + (size_t)(NP + RT * pitch) * sizeof(float);
+      const int grid = noise_cdiv(L, RT);
+      if (n_partial) *n_partial = grid;
+      const float scale = (float)(1.0 / ((double)B * (double)B * (double)L));
+      hipStream_t st = (hipStream_t)stream;
+#define ROWS(ept)                                                                                                  \
+  do {                                                                                                             \
+    NOISE_ALLOW_LDS(wave_pair_rows_kernel<ept>, smem);                                                             \
+    hipLaunchKernelGGL(wave_pair_rows_kernel<ept>, dim3(grid), dim3(256), smem, st, wave, clean, B, L, scale,      \
+                       d_wave, partial);                                                                           \
+  } while (0)
+      if (NP == 256) ROWS(1);
+      else if (NP == 512) ROWS(2);
+      else if (NP == 1024) ROWS(4);
+      else ROWS(8);
+#undef ROWS
+      NOISE_CHECK_LAUNCH("noise_wave_pair_l1/rows");
+      return 0;
+    }
     // columns per workgroup: the kernel is a chain of barriers and dependent LDS reads, so several small
     // workgroups per CU (<= 40 KiB of LDS each) hide far more latency than one large one
     const size_t per_col = (size_t)(B + 1) * sizeof(double) + (size_t)NP * sizeof(float);

@@ -15,7 +15,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,L", [(3, 100), (17, 1000), (64, 777), (100, 800), (257, 64), (1280, 96), (2048, 40), (2100, 33)])
+@pytest.mark.parametrize("B,L", [(3, 100), (17, 1000), (64, 777), (100, 800), (129, 50), (257, 64), (300, 61), (600, 24),
+                                 (1280, 96), (1280, 101), (2048, 40), (2100, 33)])
 def test_wave_pair_l1(dev, B, L):
     """mean over all (i,j,t) of |w_i[t] - c_j[t]| and its gradient, brute-force (small / huge B) and sorted paths;
     ties (clamped +-1 samples, silent clips) must give sign 0 exactly like torch's L1 subgradient."""
