@@ -735,15 +735,18 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
 }
 
 // LayerNorm backward on a tile: g (LDS, in/out: dL/d(ln out) -> dL/d(ln in)), xhat tile (LDS), gamma (LDS).
-// Also accumulates column sums for dgamma / dbeta into per-thread registers of threads c < D.
+// Also accumulates column sums for dgamma / dbeta into per-thread registers: thread (wave w, lane c) holds the part of
+// column c that comes from rows 16w..16w+15 of every tile (sum the four waves with cols_over_waves at the end).
 __device__ __forceinline__ void ln_bwd_tile(float* g, const float* xh, const float* gamma, const float* rstd_g, long tok0,
                                             long ntok, float& dgam, float& dbet) {
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
-  if (tid < D) {
+  {   // column sums: wave w takes rows 16w..16w+15 of column (tid & 63); the waves' partials meet at the kernel's end
+    const int col = tid & (D - 1), r0 = (tid >> 6) * (TT / 4);
     float sg = 0.f, sb = 0.f;
-    for (int tt = 0; tt < TT; ++tt) {
-      const float gv = g[tt * XS + tid];
-      sg = fmaf(gv, xh[tt * XS + tid], sg);
+#pragma unroll
+    for (int tt = 0; tt < TT / 4; ++tt) {
+      const float gv = g[(r0 + tt) * XS + col];
+      sg = fmaf(gv, xh[(r0 + tt) * XS + col], sg);
       sb += gv;
     }
     dgam += sg;
@@ -766,6 +769,15 @@ __device__ __forceinline__ void ln_bwd_tile(float* g, const float* xh, const flo
     const int c = part * (D / 4) + k;
     g[t * XS + c] = rs * (g[t * XS + c] * gamma[c] - a - xh[t * XS + c] * bsum);
   }
+}
+
+// Sum over the four waves of a per-(wave, column) partial; valid in threads tid < D.  red: 4*D floats of LDS.
+__device__ __forceinline__ float cols_over_waves(float v, float* red) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  red[tid] = v;
+  __syncthreads();
+  return tid < D ? (red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]) : 0.f;
 }
 
 // slab row layout of attn_post_bwd (floats): dW2[D*D] dW1[D*D] dWfc[D*HD] then 7 vectors of D:
@@ -822,20 +834,23 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
         ta[t * XS + c] = fmaf(dv, vec[2 * D + c], ta[t * XS + c]);
       }
     }
-    if (tid < D) {   // dvad_w[c] += sum over clips dv * x3[token0][c]
-      for (int tt = 0; tt < TT; ++tt)
+    {   // dvad_w[c] += sum over clips dv * x3[token0][c]; rows split over the waves like the other column sums
+      const int col = tid & (D - 1), r0 = (tid >> 6) * (TT / 4);
+      for (int tt = r0; tt < r0 + TT / 4; ++tt)
         if (tok0 + tt < d.ntok && (tok0 + tt) % d.n == 0) {
           const float dv = d_vad[(tok0 + tt) / d.n];
-          dvw = fmaf(dv, x3[(tok0 + tt) * D + tid], dvw);
-          if (tid == 0) dvb += dv;
+          dvw = fmaf(dv, x3[(tok0 + tt) * D + col], dvw);
+          if (col == 0) dvb += dv;
         }
     }
     __syncthreads();
     ln_bwd_tile(ta, tb, vec + D, rstd2, tok0, d.ntok, dg2, db2ln);   // ta = dy2
     __syncthreads();
-    if (tid < D) {
+    {
+      const int col = tid & (D - 1), r0 = (tid >> 6) * (TT / 4);
       float s = 0.f;
-      for (int tt = 0; tt < TT; ++tt) s += ta[tt * XS + tid];
+#pragma unroll
+      for (int tt = 0; tt < TT / 4; ++tt) s += ta[(r0 + tt) * XS + col];
       dbias2 += s;
     }
     tile_outer_mfma<4>(aW2, ta, XS, wave, tc, XS);                     // dW2 += dy2^T hdn
@@ -850,9 +865,11 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
     __syncthreads();
     tile_load(tb, XS, xhat1, tok0, d.ntok, D);    // tb = xhat1
     __syncthreads();
-    if (tid < D) {
+    {
+      const int col = tid & (D - 1), r0 = (tid >> 6) * (TT / 4);
       float s = 0.f;
-      for (int tt = 0; tt < TT; ++tt) s += td[tt * XS + tid];
+#pragma unroll
+      for (int tt = 0; tt < TT / 4; ++tt) s += td[(r0 + tt) * XS + col];
       dbias1 += s;
     }
     // tc = x2 = ln1_w*xhat1 + ln1_b
@@ -882,6 +899,14 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(const float* __restr
   store_outer_mfma<4>(row, D, aW2, wave, D, D);
   store_outer_mfma<4>(row + D * D, D, aW1, wave, D, D);
   store_outer_mfma<4>(row + 2 * D * D, HD, aFc, wave, D, HD);
+  dg2 = cols_over_waves(dg2, ta);
+  db2ln = cols_over_waves(db2ln, ta);
+  dbias2 = cols_over_waves(dbias2, ta);
+  dbias1 = cols_over_waves(dbias1, ta);
+  dg1 = cols_over_waves(dg1, ta);
+  db1ln = cols_over_waves(db1ln, ta);
+  dvw = cols_over_waves(dvw, ta);
+  dvb = cols_over_waves(dvb, ta);
   if (tid < D) {
     float* v = row + 2 * D * D + D * HD;
     v[tid] = dg2; v[D + tid] = db2ln; v[2 * D + tid] = dbias2; v[3 * D + tid] = dbias1;
@@ -955,6 +980,8 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(const float* __restri
   float* row = slab + (size_t)blockIdx.x * (O * D + 2 * D);
 #pragma unroll
   for (int r = 0; r < 3; ++r) store_outer_mfma<4>(row, D, aW[r], wave + 4 * r, O, D);
+  dg0 = cols_over_waves(dg0, ta);
+  db0 = cols_over_waves(db0, ta);
   if (tid < D) {
     row[O * D + tid] = dg0;
     row[O * D + D + tid] = db0;
