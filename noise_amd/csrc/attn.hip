@@ -115,27 +115,39 @@ __device__ __forceinline__ void store_outer_mfma(float* dst, int ldk, const f32x
     }
 }
 
+// Token tiles move as 16-byte pieces (widths and pitches are multiples of 4 floats), from clamped (always valid)
+// addresses with a select afterwards, so the loads of a tile are independent and issued together.
 __device__ __forceinline__ void tile_store(float* g, const float* tile, int pitch, long tok0, long ntok, int width) {
   // coalesced copy of a [TT][width] LDS tile (row pitch `pitch`) to global rows of `width` floats
-  for (int i = threadIdx.x; i < TT * width; i += 256) {
-    const int t = i / width, c = i - t * width;
-    if (tok0 + t < ntok) g[(tok0 + t) * width + c] = tile[t * pitch + c];
+  const int w4 = width >> 2;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < TT * w4; i += 256) {
+    const int t = i / w4, c = 4 * (i - t * w4);
+    if (tok0 + t < ntok) st4(g + (tok0 + t) * width + c, ld4(tile + t * pitch + c));
   }
 }
 
 __device__ __forceinline__ void tile_load(float* tile, int pitch, const float* g, long tok0, long ntok, int width) {
-  for (int i = threadIdx.x; i < TT * width; i += 256) {
-    const int t = i / width, c = i - t * width;
-    tile[t * pitch + c] = (tok0 + t < ntok) ? g[(tok0 + t) * width + c] : 0.f;
+  const int w4 = width >> 2;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < TT * w4; i += 256) {
+    const int t = i / w4, c = 4 * (i - t * w4);
+    const bool in = tok0 + t < ntok;
+    const float4 v = ld4(g + (in ? tok0 + t : ntok - 1) * width + c);
+    st4(tile + t * pitch + c, in ? v : f4(0.f));
   }
 }
 
 // like tile_load, and columns [width, padded) are zeroed (they feed MFMA k-steps)
 __device__ __forceinline__ void tile_load_padded(float* tile, int pitch, const float* g, long tok0, long ntok, int width,
                                                  int padded) {
-  for (int i = threadIdx.x; i < TT * padded; i += 256) {
-    const int t = i / padded, c = i - t * padded;
-    tile[t * pitch + c] = (tok0 + t < ntok && c < width) ? g[(tok0 + t) * width + c] : 0.f;
+  const int p4 = padded >> 2;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < TT * p4; i += 256) {
+    const int t = i / p4, c = 4 * (i - t * p4);
+    const bool in = tok0 + t < ntok && c < width;
+    const float4 v = ld4(g + (tok0 + t < ntok ? tok0 + t : ntok - 1) * width + (c < width ? c : 0));
+    st4(tile + t * pitch + c, in ? v : f4(0.f));
   }
 }
 
