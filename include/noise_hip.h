@@ -113,6 +113,7 @@ int noise_pw_wgrad(const float* dz, const float* y_out, const float* coef3, cons
                    long npix, int Cout, int Cin, void* stream);
 
 int noise_pw_bwd_max_rows(int Cout, int Cin);   /* slab rows noise_pw_bwd may use for a Cout x Cin layer */
+int noise_pw_bwd_reads_y(int Cout, int Cin);    /* 0: y_out is recomputed from the layer input (expanding layers), never read */
 /* fused dgrad + wgrad of a pointwise layer; stats_slab (with epi_coef) receives *slab_rows rows of 2*Cin floats;
  * scratch >= noise_pw_bwd_max_rows(Cout, Cin)*Cout*Cin floats, stats_slab that many rows */
 int noise_pw_bwd(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,

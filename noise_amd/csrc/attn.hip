@@ -421,6 +421,17 @@ template <int DK4>
 __device__ __forceinline__ void stage_head(float* dst, const float* __restrict__ src, long base, int ld, int col0, int n,
                                            int dk, float scale_div) {
   constexpr int DKP = DK4 * 4;
+  if (dk == DKP && ((ld | col0) & 3) == 0) {
+    // whole 16-byte pieces: all of a lane's loads are independent and issued together
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n * DK4; i += AW) {
+      const int j = i / DK4, c4 = i - j * DK4;
+      float4 v = ld4(src + (base + j) * ld + col0 + 4 * c4);
+      if (scale_div != 0.f) v = make_float4(v.x / scale_div, v.y / scale_div, v.z / scale_div, v.w / scale_div);
+      st4(dst + 4 * i, v);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < n * DKP; i += AW) {
     const int j = i / DKP, c = i - j * DKP;
     float v = 0.f;
@@ -430,6 +441,21 @@ __device__ __forceinline__ void stage_head(float* dst, const float* __restrict__
     }
     dst[i] = v;
   }
+}
+
+// a lane's row of one head to / from global memory (columns >= dk are padding)
+template <int DK4>
+__device__ __forceinline__ void store_head_row(float* dst, const float (&v)[DK4 * 4], int dk, float div) {
+  if (dk == DK4 * 4 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+#pragma unroll
+    for (int c4 = 0; c4 < DK4; ++c4)
+      st4(dst + 4 * c4, div != 0.f ? make_float4(v[4 * c4] / div, v[4 * c4 + 1] / div, v[4 * c4 + 2] / div, v[4 * c4 + 3] / div)
+                                    : make_float4(v[4 * c4], v[4 * c4 + 1], v[4 * c4 + 2], v[4 * c4 + 3]));
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < DK4 * 4; ++c)
+    if (c < dk) dst[c] = div != 0.f ? v[c] / div : v[c];
 }
 
 template <int DK4>
@@ -565,13 +591,10 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
   for (int c = 0; c < DKP; ++c) dkk[c] = 0.f;
   for (int r = 0; r < n; ++r) axpy_row<DK4>(M[r * mp + ic], qs + r * DKP, dkk);
   if (act) {
-#pragma unroll
-    for (int c = 0; c < DKP; ++c)
-      if (c < dk) {
-        d_qkv[(base + i) * O + h * dk + c] = dq[c] / temp;
-        d_qkv[(base + i) * O + d.hd + h * dk + c] = dkk[c];
-        d_qkv[(base + i) * O + 2 * d.hd + h * dk + c] = dvv[c];
-      }
+    float* row = d_qkv + (base + i) * O + h * dk;
+    store_head_row<DK4>(row, dq, dk, temp);
+    store_head_row<DK4>(row + d.hd, dkk, dk, 0.f);
+    store_head_row<DK4>(row + 2 * d.hd, dvv, dk, 0.f);
   }
 }
 

@@ -294,7 +294,13 @@ constexpr int pw_bwd_min_blocks(int KC, int MTI) {
 // rows of the 64-pixel tile a thread stages when a row has `tiles` 16-channel tiles (see the staging map below)
 constexpr int pw_bwd_passes(int tiles) { return (WG_TILE + 256 / (tiles * 4) - 1) / (256 / (tiles * 4)); }
 
-template <int KC, int MTI, bool HAS_B>
+// RY (expanding layers with at most 16 input channels, BatchNorm behind the layer; with more input channels the extra
+// MFMAs and barrier cost more than the read they save): the raw layer output y that the lazy
+// gradient needs (dy = s*(dz - k1) + a2*(y - mean)) is recomputed from the staged input tile, y = a W^T (KC*MTI*4
+// MFMAs per wave and tile), instead of being read back: the widest tensor of the layer is read once (dz), not twice.
+constexpr bool pw_bwd_recompute(int KC, int MTI) { return MTI == 1 && KC >= 2; }
+
+template <int KC, int MTI, bool HAS_B, bool RY>
 __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bs, const float* __restrict__ W,
                                                      float* __restrict__ g_in, BwdEpilogue E, float* __restrict__ dw_slab,
                                                      long npix, int N, int K) {
@@ -307,10 +313,15 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
   float* dys = wfrag + MTI * KC * 256;           // [64][pn]
   float* as = dys + WG_TILE * pn;                // [64][pk]
   float* ecf = as + WG_TILE * pk;                // [5][KP] producer BN coefficients for the epilogue
+  float* wfy = ecf + 5 * KP;                     // RY: [KC][MTI][64][4] forward fragment image of W
+  float* gcf = wfy + KC * MTI * 256;             // RY: [6][NP] lazy-gradient coefficients (0 for padded channels)
   // W is read once, row by row, with coalesced 16-byte loads and scattered into the fragment image
   // ([m][jj][lane = ci%16 + 16*((co%16)/4)][co%4])
   if ((N & 15) || (K & 15)) {
-    for (int idx = tid; idx < MTI * KC * 256; idx += 256) wfrag[idx] = 0.f;
+    for (int idx = tid; idx < MTI * KC * 256; idx += 256) {
+      wfrag[idx] = 0.f;
+      if (RY) wfy[idx] = 0.f;
+    }
     __syncthreads();
   }
   {
@@ -324,6 +335,13 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
       dst[4] = v.y;
       dst[8] = v.z;
       dst[12] = v.w;
+      if (RY) st4(wfy + ((((co >> 4) * MTI + (ci >> 4)) * 64) + (co & 15) + 16 * ((ci & 15) >> 2)) * 4, v);
+    }
+  }
+  if (RY) {
+    for (int k = tid; k < 6 * NP; k += 256) {
+      const int j = k / NP, c = k - j * NP;
+      gcf[k] = c < N ? G.coef3[j * N + c] : 0.f;
     }
   }
   for (int k = tid; k < KP; k += 256) {
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
         pix = pix < npix ? pix : npix - 1;
         const size_t off = (size_t)pix * N + cnc;
         rz[u] = ld4(G.dz + off);
-        ry[u] = G.coef3 ? ld4(G.y + off) : f4(0.f);
+        ry[u] = (G.coef3 && !RY) ? ld4(G.y + off) : f4(0.f);
       }
 #pragma unroll
       for (int u = 0; u < PASS_K; ++u) {
@@ -419,7 +437,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
           const int pp = rn + u * RN;
           if (pp < WG_TILE) {
             float4 v = rz[u];
-            if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
+            if (G.coef3 && !RY) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
             st4(dys + pp * pn + cn, (on && pp < left) ? v : f4(0.f));
           }
         }
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
             pix = pix < npix ? pix : npix - 1;
             const size_t off = (size_t)pix * N + cnc;
             rz[u] = ld4(G.dz + off);
-            ry[u] = G.coef3 ? ld4(G.y + off) : f4(0.f);
+            ry[u] = (G.coef3 && !RY) ? ld4(G.y + off) : f4(0.f);
           }
         }
 #pragma unroll
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
           const int pp = rn + (ps0 + u) * RN;
           if (ps0 + u < PASS_N && pp < WG_TILE) {
             float4 v = rz[u];
-            if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
+            if (G.coef3 && !RY) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
             st4(dys + pp * pn + cn, (on && pp < left) ? v : f4(0.f));
           }
         }
@@ -500,6 +518,36 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     }
     }
     __syncthreads();
+    float4 in[KC];   // dy of this wave's 16 pixels: lane (p, q) holds channels 16jj + 4q .. + 3 of pixel p
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) in[jj] = ld4(dys + (16 * wave + p) * pn + 16 * jj + 4 * q);
+    if (RY) {
+      // y = a W^T for these pixels (D[i = co][j = pixel]: the lane receives exactly the channels it holds of dz),
+      // then the lazy BatchNorm backward; the finished dy goes back to the staged tile for the weight gradient
+      const bool live = tile < ntiles && pix0 + 16 * wave + p < npix;
+      float4 av[MTI];
+#pragma unroll
+      for (int m = 0; m < MTI; ++m) av[m] = ld4(as + (16 * wave + p) * pk + 16 * m + 4 * q);
+#pragma unroll
+      for (int jj = 0; jj < KC; ++jj) {
+        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MTI; ++m) {
+          const float4 wa = ld4(wfy + ((jj * MTI + m) * 64 + lane) * 4);
+          y = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, av[m].x, y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, av[m].y, y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, av[m].z, y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, av[m].w, y, 0, 0, 0);
+        }
+        const int co = 16 * jj + 4 * q;
+        const float4 yv = make_float4(y[0], y[1], y[2], y[3]);
+        const float4 t1 = sub4(sub4(in[jj], ld4(gcf + NP + co)), ld4(gcf + 2 * NP + co));
+        const float4 t2 = sub4(sub4(yv, ld4(gcf + 4 * NP + co)), ld4(gcf + 5 * NP + co));
+        const float4 v = fma4(ld4(gcf + 3 * NP + co), t2, ld4(gcf + co) * t1);
+        in[jj] = live ? v : f4(0.f);
+        st4(dys + (16 * wave + p) * pn + co, in[jj]);
+      }
+    }
     // ---- dgrad for this wave's 16 pixels
     if (g_in != nullptr) {
       const long pix = pix0 + 16 * wave + p;
@@ -517,9 +565,6 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
           go[m] = ld4(gop + (prow + cic) * gmul);
         }
       }
-      float4 in[KC];
-#pragma unroll
-      for (int jj = 0; jj < KC; ++jj) in[jj] = ld4(dys + (16 * wave + p) * pn + 16 * jj + 4 * q);
 #pragma unroll
       for (int m = 0; m < MTI; ++m) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -554,6 +599,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
         }
       }
     }
+    if (RY) __syncthreads();   // every wave has put its finished dy rows back
     // ---- wgrad: 16 k-steps of 4 pixels over this wave's tiles
 #pragma unroll 2
     for (int s = 0; s < 16; ++s) {
@@ -709,6 +755,9 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
   if ((size_t)Cout * Cin * sizeof(float) > smem) smem = (size_t)Cout * Cin * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   bool done = false;
+  // NOISE_PW_NO_RECOMPUTE (diagnostic): always read the layer's raw output back
+  static const bool recompute_off = getenv("NOISE_PW_NO_RECOMPUTE") != nullptr;
+  const bool recompute = coef3 != nullptr && !recompute_off;
 #define X(nt, mt)                                                                                                      \
   if constexpr (mt * nt <= 48) {                                                                                       \
     if (!done && MT == mt && NT == nt) {                                                                               \
@@ -735,6 +784,11 @@ NOISE_EXPORT int noise_pw_bwd_max_rows(int Cout, int Cin) {
   return (int)cap;
 }
 
+// 1 when noise_pw_bwd reads y_out for a Cout x Cin layer with coef3, 0 when it recomputes it from the layer input.
+NOISE_EXPORT int noise_pw_bwd_reads_y(int Cout, int Cin) {
+  return pw_bwd_recompute((Cout + 15) / 16, (Cin + 15) / 16) && getenv("NOISE_PW_NO_RECOMPUTE") == nullptr ? 0 : 1;
+}
+
 // Fused backward of a pointwise layer (see pw_bwd_kernel): g_in (npix, Cin) and dw (Cout, Cin) from one pass.
 // Epilogue (optional): g_in += g_other; with epi_coef (BatchNorm coefficients of source a's producer) g_in is
 // masked by the producer's ReLU6 (epi_relu6) and stats_slab receives *slab_rows rows of [sum dz | sum dz*xhat]
@@ -758,17 +812,35 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
   NOISE_REQUIRE(smem <= 160 * 1024, "noise_pw_bwd: %dx%d layer needs %zu bytes of LDS", Cout, Cin, smem);
   hipStream_t st = (hipStream_t)stream;
   bool done = false;
+  // NOISE_PW_NO_RECOMPUTE (diagnostic): always read the layer's raw output back
+  static const bool recompute_off = getenv("NOISE_PW_NO_RECOMPUTE") != nullptr;
+  const bool recompute = coef3 != nullptr && !recompute_off;
 #define X(nt, mt)                                                                                                       \
   if constexpr (mt * nt <= 48) {                                                                                        \
     if (!done && KC == mt && MTI == nt) {                                                                               \
-      if (b_y != nullptr) {                                                                                             \
-        NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, true>), smem);                                                           \
-        NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, true>), grid, smem, st, G, A, Bs, w, g_in, E, scratch, npix, Cout,   \
-                            Cin);                                                                                       \
-      } else {                                                                                                          \
-        NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, false>), smem);                                                          \
-        NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, false>), grid, smem, st, G, A, Bs, w, g_in, E, scratch, npix, Cout,  \
-                            Cin);                                                                                       \
+      if constexpr (pw_bwd_recompute(mt, nt)) {                                                                         \
+        if (recompute) {                                                                                                \
+          const size_t sm2 = smem + (size_t)(mt * nt * 256 + 6 * mt * 16) * sizeof(float);                              \
+          if (b_y != nullptr) {                                                                                         \
+            NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, true, true>), sm2);                                                  \
+            NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, true, true>), grid, sm2, st, G, A, Bs, w, g_in, E, scratch,      \
+                                npix, Cout, Cin);                                                                       \
+          } else {                                                                                                      \
+            NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, false, true>), sm2);                                                 \
+            NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, false, true>), grid, sm2, st, G, A, Bs, w, g_in, E, scratch,     \
+                                npix, Cout, Cin);                                                                       \
+          }                                                                                                             \
+          done = true;                                                                                                  \
+        }                                                                                                               \
+      }                                                                                                                 \
+      if (!done && b_y != nullptr) {                                                                                    \
+        NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, true, false>), smem);                                                    \
+        NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, true, false>), grid, smem, st, G, A, Bs, w, g_in, E, scratch, npix,  \
+                            Cout, Cin);                                                                                 \
+      } else if (!done) {                                                                                               \
+        NOISE_ALLOW_LDS((pw_bwd_kernel<mt, nt, false, false>), smem);                                                   \
+        NOISE_LAUNCH_ROUNDS((pw_bwd_kernel<mt, nt, false, false>), grid, smem, st, G, A, Bs, w, g_in, E, scratch, npix, \
+                            Cout, Cin);                                                                                 \
       }                                                                                                                 \
       done = true;                                                                                                      \
     }                                                                                                                   \

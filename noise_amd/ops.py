@@ -156,9 +156,11 @@ def pw_bwd(grad, a, b, w, g_in, dw, scratch, npix, Cout, Cin, g_other=None, epi=
     """Fused dgrad + wgrad (+ producer BatchNorm-backward sums into stats_slab when epi is given).  Returns rows."""
     dz, y, coef3 = grad
     rows = ctypes.c_int(0)
+    # expanding layers recompute their raw output from the staged input tile instead of reading it back
+    reads_y = coef3 is not None and bool(_lib.lib.noise_pw_bwd_reads_y(Cout, Cin))
     _lib.call("noise_pw_bwd", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(w), ptr(g_in), ptr(dw), ptr(scratch),
               ptr(g_other), *_epi(epi), ptr(stats_slab), ctypes.byref(rows), npix, Cout, Cin, _lib.stream(),
-              nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin * (_nsrc(b) + 1 + (g_other is not None))))
+              nbytes=4 * npix * (Cout * (2 if reads_y else 1) + Cin * (_nsrc(b) + 1 + (g_other is not None))))
     return rows.value
 
 
