@@ -78,13 +78,13 @@ MAIN_KERNEL = {"noise_pw_bwd": "pw_bwd_kernel", "noise_pw_fwd": "pw_gemm_kernel"
                "noise_last_convT_fwd": "last_cell_fwd_kernel", "noise_stft_fwd": "stft_frames_kernel"}
 
 
-def pmc_traffic(entry_point):
+def pmc_traffic(entry_point, clips=64):
     """HBM bytes per launch of the entry point's main kernel, from the committed PMC passes of this same command
     (profiles/r1_hbm_traffic_per_kernel.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
     FETCH_SIZE doubled as gfx950 requires); None when no such profile is available."""
     path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_per_kernel.json")
     kernel = MAIN_KERNEL.get(entry_point)
-    if kernel is None or not os.path.exists(path):
+    if kernel is None or clips != 64 or not os.path.exists(path):   # the passes were taken on the default workload
         return None
     with open(path) as f:
         rec = json.load(f).get(kernel)
@@ -180,7 +180,7 @@ def main():
 
     achieved = dbytes / 1e6 / dms  # bytes / ms -> GB/s
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.clips),
                 "algorithmic_bytes_per_launch": int(dbytes / dn),
                 "launches_per_step": dn // args.steps, "avg_launch_ms": round(dms / dn, 4),
                 "share_of_step": round(dms / args.steps / step_ms, 3),
