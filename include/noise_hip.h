@@ -27,7 +27,7 @@ int noise_version(void);
 
 /* ---- STFT / iSTFT: train/models.py:460-475 (STFT.forward), :477-495 (STFT.inverse) ---------- */
 int noise_stft_rpad(int n_fft);       /* row count of the interleaved, transposed basis layout */
-/* wave [B][L] -> logmag, phase [B][F][T], T = L/hop + 1; absmax [B] (optional) = max |logmag| per clip
+/* wave [B][L] -> logmag, phase [B][F][T] (phase optional: NULL skips it), T = L/hop + 1; absmax [B] (optional) = max |logmag| per clip
  * (models.py:614-620).  basisT [n_fft][rpad]: column 2f = Re row f, 2f+1 = Im row f of forward_basis. */
 int noise_stft_fwd(const float* wave, const float* basisT, float* logmag, float* phase, float* absmax,
                    int B, int L, int n_fft, int hop, void* stream);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(
           if (MODE == 0) {
             const float lm = logf(fmaxf(sqrtf(re * re + im * im), 1e-3f));
             out0[o] = lm;
-            out1[o] = atan2f(im, re);
+            if (out1 != nullptr) out1[o] = atan2f(im, re);
             amax = fmaxf(amax, fabsf(lm));
           } else {
             float sn, cs;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * STFT_SYM_MAX_WAVES) void stft_frames_sym_kerne
         if (MODE == 0) {
           const float lm = logf(fmaxf(sqrtf(re * re + im * im), 1e-3f));
           out0[o] = lm;
-          out1[o] = atan2f(im, re);
+          if (out1 != nullptr) out1[o] = atan2f(im, re);
           amax = fmaxf(amax, fabsf(lm));
         } else {
           float sn, cs;
@@ -513,7 +513,7 @@ NOISE_EXPORT int noise_stft_rpad(int n_fft) { return ((2 * (n_fft / 2 + 1) + 31)
 NOISE_EXPORT int noise_stft_fwd(const float* wave, const float* basisT, float* logmag, float* phase,
                                 float* absmax, int B, int L, int n_fft, int hop, void* stream) {
   if (check_dims("noise_stft_fwd", B, L, n_fft, hop)) return -1;
-  NOISE_REQUIRE(wave && basisT && logmag && phase, "noise_stft_fwd: null pointer");
+  NOISE_REQUIRE(wave && basisT && logmag, "noise_stft_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   StftDims d{B, L, L / hop + 1, n_fft, hop, n_fft / 2 + 1, noise_stft_rpad(n_fft), hop * (L / hop), 0};
   if (absmax) {
@@ -578,7 +578,7 @@ NOISE_EXPORT int noise_stft_fold_cols(int n_fft) { return 2 * 32 * ((n_fft / 2 +
 NOISE_EXPORT int noise_stft_fwd_sym(const float* wave, const float* basisF, float* logmag, float* phase,
                                     float* absmax, int B, int L, int n_fft, int hop, void* stream) {
   if (check_dims("noise_stft_fwd_sym", B, L, n_fft, hop)) return -1;
-  NOISE_REQUIRE(wave && basisF && logmag && phase, "noise_stft_fwd_sym: null pointer");
+  NOISE_REQUIRE(wave && basisF && logmag, "noise_stft_fwd_sym: null pointer");
   hipStream_t st = (hipStream_t)stream;
   StftDims d{B, L, L / hop + 1, n_fft, hop, n_fft / 2 + 1, 0, hop * (L / hop), 0, 0, 0};
   if (absmax) {

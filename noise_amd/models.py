@@ -412,7 +412,7 @@ class VADSpectralV2(_LightningModule):
         # the network input keeps the reference's accumulation order (see STFT.forward): its per-clip normaliser is
         # sensitive to fp32 rounding, and gradients are compared against the reference's
         lm_n, ph, absmax = stft.forward(noisy.view(B, 1, 1, seg), return_absmax=True, reference_order=True)
-        lm_c, _ = stft.forward(clean.view(B, 1, 1, seg))
+        lm_c, _ = stft.forward(clean.view(B, 1, 1, seg), want_phase=False)
         _, _, H, W = lm_n.shape
         training = self.training
         plan, enh, vad = self._spectral(lm_n, absmax, training, keep, self._next_seed())

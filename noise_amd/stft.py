@@ -134,7 +134,7 @@ class STFT(torch.nn.Module):
     def num_frames(self, L):
         return L // self.hop_length + 1
 
-    def forward(self, waveform, return_absmax=False, reference_order=False):
+    def forward(self, waveform, return_absmax=False, reference_order=False, want_phase=True):
         """`reference_order=True` takes the general kernel, which accumulates every bin over the n_fft samples in
         the order of the reference's conv1d, even when the folded one is available.  The two agree to fp32
         rounding (the folded one is slightly closer to a float64 evaluation), but on bins near the 1e-3 magnitude
@@ -150,11 +150,12 @@ class STFT(torch.nn.Module):
         sym, basisT, _, basisF, _ = self._bases()
         sym = sym and not reference_order
         logmag = torch.empty(B, 1, self.cutoff, T, device=wave.device, dtype=torch.float32)
-        phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32)
+        # a caller that only needs the magnitudes (the clean target of the spectral loss) skips atan2 and its store
+        phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32) if want_phase else None
         absmax = torch.empty(B, device=wave.device, dtype=torch.float32) if return_absmax else None
         _lib.call("noise_stft_fwd_sym" if sym else "noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisF if sym else basisT), _lib.ptr(logmag), _lib.ptr(phase),
                   _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream(),
-                  nbytes=4 * B * L + 8 * B * self.cutoff * T)
+                  nbytes=4 * B * L + (8 if want_phase else 4) * B * self.cutoff * T)
         if return_absmax:
             return logmag, phase, absmax
         return logmag, phase
