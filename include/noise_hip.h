@@ -56,6 +56,17 @@ int noise_istft_bwd_sym(const float* d_wave, const float* wave_out, const float*
                         const float* inv_basisF, const float* window_sum, float* d_logmag, int accumulate,
                         int B, int T, int n_fft, int hop, void* stream);
 
+/* ---- deferred folds of per-workgroup slabs (no counterpart in the reference: ATen reduces inside each op) ------ */
+/* out[j] = sum over rows of slab[row*row_stride + j], j < ncols; with tr_k > 0 column j = k*tr_C + c goes to
+ * out[c*tr_k + k] (the (C, k) layout of a depthwise weight).  noise_pw_bwd and noise_dw3x3_bwd called with dw = NULL
+ * leave their weight-gradient slab unfolded; one noise_fold_jobs call (jobs: DEVICE array) folds them all. */
+typedef struct {
+  const float* slab;
+  float* out;
+  int rows, ncols, row_stride, tr_k, tr_C;
+} noise_fold_job;
+int noise_fold_jobs(const noise_fold_job* jobs, int njobs, int max_cols, void* stream);
+
 /* ---- SNR mixer: process/audiolib.py:176-216 (+ :219-248, :30-35, :18-19), :251-289 ---------- */
 /* clean, noise [U][L] float64 (already length-matched); snr, level_draw [U]; outputs [U][L], level_out [U] */
 int noise_snr_mix(const double* clean, const double* noise, const int* snr, const int* level_draw,

@@ -9,6 +9,7 @@
 // the consumer's loader (LazySrc), and the per-channel sum / sum-of-squares needed for train-mode
 // batch statistics come out of the same pass as per-workgroup partials (no atomics).
 #include "lazy.h"
+#include "noise_hip.h"
 
 namespace {
 
@@ -454,6 +455,42 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   out[o] = accumulate ? out[o] + (float)s : (float)s;
 }
 
+// The same fold for a table of slabs in one launch: blockIdx.y = job.  A workgroup takes FOLD_COLS = 16 columns (64
+// contiguous bytes of every row) with 16 row lanes, four independent double accumulators per thread.
+constexpr int FOLD_COLS = 16;
+__global__ __launch_bounds__(256) void fold_jobs_kernel(const noise_fold_job* __restrict__ jobs) {
+  __shared__ double red[256];
+  const noise_fold_job jb = jobs[blockIdx.y];
+  if ((int)blockIdx.x * FOLD_COLS >= jb.ncols) return;
+  constexpr int LANES = 256 / FOLD_COLS;
+  const int cl = threadIdx.x & (FOLD_COLS - 1), rl = threadIdx.x / FOLD_COLS;
+  const int j = blockIdx.x * FOLD_COLS + cl;
+  const bool ok = j < jb.ncols;
+  const float* col = jb.slab + (ok ? j : 0);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int r = rl;
+  for (; r + 3 * LANES < jb.rows; r += 4 * LANES) {
+    a0 += (double)col[(size_t)r * jb.row_stride];
+    a1 += (double)col[(size_t)(r + LANES) * jb.row_stride];
+    a2 += (double)col[(size_t)(r + 2 * LANES) * jb.row_stride];
+    a3 += (double)col[(size_t)(r + 3 * LANES) * jb.row_stride];
+  }
+  for (; r < jb.rows; r += LANES) a0 += (double)col[(size_t)r * jb.row_stride];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x >= FOLD_COLS || !ok) return;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < LANES; ++k) s += red[threadIdx.x + FOLD_COLS * k];
+  int o = j;
+  if (jb.tr_k > 0) {
+    const int k = j / jb.tr_C, c = j - k * jb.tr_C;
+    if (k >= jb.tr_k) return;
+    o = c * jb.tr_k + k;
+  }
+  jb.out[o] = (float)s;
+}
+
 int conv_grid(long npix, int C) {
   const int PPB = 256 / (C / 4);
   return noise_grid(npix, PPB * 4, 1024);
@@ -544,7 +581,7 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   if (check_c("noise_dw3x3_bwd", C)) return -1;
   NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "noise_dw3x3_bwd: empty input");
   NOISE_REQUIRE((sy == 1 || sy == 2) && (sx == 1 || sx == 2), "noise_dw3x3_bwd: stride must be 1 or 2");
-  NOISE_REQUIRE(dz && a_y && w && dw && scratch, "noise_dw3x3_bwd: null pointer");
+  NOISE_REQUIRE(dz && a_y && w && scratch, "noise_dw3x3_bwd: null pointer");
   NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_dw3x3_bwd: coef3 needs y_out");
   ConvDims d;
   d.B = B; d.Hi = Hi; d.Wi = Wi; d.C = C; d.sy = sy; d.sx = sx;
@@ -611,8 +648,20 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   }
   if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_dw3x3_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
-  NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
+  if (dw != nullptr) {   // NULL: the caller folds the slab later (noise_fold_jobs)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
+    NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
+  }
+  return 0;
+}
+
+// Folds njobs per-workgroup slabs into their destinations in one launch (jobs: device array).  The weight-gradient
+// slabs of noise_pw_bwd / noise_dw3x3_bwd called with dw = NULL are meant for this: nothing waits for a weight gradient
+// before the optimizer, so one fold at the end of the backward pass replaces one small launch per layer.
+NOISE_EXPORT int noise_fold_jobs(const noise_fold_job* jobs, int njobs, int max_cols, void* stream) {
+  NOISE_REQUIRE(jobs && njobs > 0 && max_cols > 0, "noise_fold_jobs: bad argument");
+  hipLaunchKernelGGL(fold_jobs_kernel, dim3(noise_cdiv(max_cols, FOLD_COLS), njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+  NOISE_CHECK_LAUNCH("noise_fold_jobs");
   return 0;
 }
 

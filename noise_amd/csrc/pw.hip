@@ -798,7 +798,7 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
                               const float* w, float* g_in, float* dw, float* scratch, const float* g_other,
                               const float* epi_coef, int epi_relu6, float* stats_slab, int* slab_rows, long npix,
                               int Cout, int Cin, void* stream) {
-  NOISE_REQUIRE(dz && a_y && w && g_in && dw && scratch && npix > 0, "noise_pw_bwd: bad argument");
+  NOISE_REQUIRE(dz && a_y && w && g_in && scratch && npix > 0, "noise_pw_bwd: bad argument");
   NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_pw_bwd: coef3 needs y_out");
   NOISE_REQUIRE(epi_coef == nullptr || stats_slab != nullptr, "noise_pw_bwd: epi_coef needs stats_slab");
   NOISE_REQUIRE(Cout % 4 == 0 && Cin % 4 == 0, "noise_pw_bwd: channel counts must be multiples of 4");
@@ -850,7 +850,9 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
   NOISE_REQUIRE(done, "noise_pw_bwd: no kernel instance for Cout=%d Cin=%d", Cout, Cin);
   if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_pw_bwd");
-  hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, SLAB_COLS)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
-  NOISE_CHECK_LAUNCH("noise_pw_bwd/reduce");
+  if (dw != nullptr) {   // NULL: the caller folds the slab later (noise_fold_jobs)
+    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3(noise_cdiv(Cout * Cin, SLAB_COLS)), dim3(256), 0, st, scratch, grid, Cout * Cin, dw);
+    NOISE_CHECK_LAUNCH("noise_pw_bwd/reduce");
+  }
   return 0;
 }

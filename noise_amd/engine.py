@@ -43,7 +43,7 @@ ATTN_DROPOUT = 0.1  # ScaledDotProductAttention default, never overridden by the
 class _Rec:
     """One convolution layer of the schedule and the buffers that belong to it."""
     __slots__ = ("name", "kind", "conv", "bn", "relu6", "C", "Cin", "B", "Hi", "Wi", "Ho", "Wo", "stride",
-                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "dz", "g_in")
+                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "dz", "g_in", "wslab")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -180,6 +180,13 @@ class DenoiserPlan:
         for r in self.recs:
             if r.kind != "first":
                 r.g_in = torch.empty(r.B, r.Hi, r.Wi, r.Cin, **f32)
+            # every inner layer keeps its own weight-gradient slab: nothing waits for a weight gradient before the
+            # optimizer, so the slabs are folded by ONE launch at the end of the backward pass (see _fold_weight_grads)
+            if r.kind == "pw":
+                r.wslab = torch.empty(ops.pw_bwd_max_rows(r.C, r.Cin) * r.C * r.Cin, **f32)
+            elif r.kind == "dw":
+                r.wslab = torch.empty(ops.CONV_MAX_BLOCKS * 11 * r.C, **f32)
+        self.fold_table = None      # (key, device job table, njobs, max_cols)
         nt, D, hd = self.ntok, self.d_model, self.hd
         self.d_o = torch.empty(nt, hd, **f32)
         self.d_x1 = torch.empty(nt, D, **f32)
@@ -303,15 +310,18 @@ class DenoiserPlan:
             pa, pb = producer(r.src_a), producer(r.src_b)
             g_other, epi = epilogue_for(pa)
             if r.kind == "pw":
-                rows = ops.pw_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, G(r.conv.weight), self.slab, r.npix_in,
+                rows = ops.pw_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, None, r.wslab, r.npix_in,
                                   r.C, r.Cin, g_other, epi, self.slab2)
                 finalize(pa, self.slab2, rows, 2 * r.Cin)
+                fold.append((r.wslab, G(r.conv.weight), rows, r.C * r.Cin, r.C * r.Cin, 0, 0))
             else:
-                rows = ops.dw3x3_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, G(r.conv.weight), self.slab,
+                rows = ops.dw3x3_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, None, r.wslab,
                                      r.transposed, r.B, r.Hi, r.Wi, r.C, r.stride, g_other, epi)
-                finalize(pa, self.slab[9 * r.C:], rows, 11 * r.C)
+                finalize(pa, r.wslab[9 * r.C:], rows, 11 * r.C)
+                fold.append((r.wslab, G(r.conv.weight), rows, 9 * r.C, 11 * r.C, 9, r.C))
             done(r, pa, pb)
 
+        fold = []   # (slab, destination, rows, columns, row stride, tr_k, tr_C) of every deferred weight gradient
         for layers in reversed(self.dec[:-1]):
             for r in reversed(layers):
                 layer_backward(r)
@@ -363,3 +373,17 @@ class DenoiserPlan:
         ops.first_conv_wgrad((r0.dz, r0.y, r0.coef3), self.logmag, self.absmax, G(r0.conv.weight), self.slab, self.B,
                              self.H, self.W, self.hp, self.wp, net.pad_value, r0.C, r0.stride)
         assert not pending_skip, "unconsumed skip gradients"
+        self._fold_weight_grads(fold)
+
+    def _fold_weight_grads(self, fold):
+        """One launch folds all deferred weight-gradient slabs.  The job table lives on the device and is rebuilt only
+        when a pointer or row count changes (a new gradient target, another geometry)."""
+        key = tuple((sl.data_ptr(), out.data_ptr(), rows) for sl, out, rows, *_ in fold)
+        if self.fold_table is None or self.fold_table[0] != key:
+            jobs = (ops.FoldJob * len(fold))()
+            for j, (sl, out, rows, ncols, stride, tr_k, tr_C) in enumerate(fold):
+                jobs[j] = ops.FoldJob(sl.data_ptr(), out.data_ptr(), rows, ncols, stride, tr_k, tr_C)
+            host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+            self.fold_table = (key, host.to(self.device), len(fold), max(f[3] for f in fold))
+        _, table, njobs, max_cols = self.fold_table
+        _lib.call("noise_fold_jobs", ptr(table), njobs, max_cols, _lib.stream())

@@ -15,6 +15,7 @@ from ._lib import ptr
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 _lib.register({
+    "noise_fold_jobs": [_P, _I, _I, _P],
     "noise_dw3x3_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_dw3x3_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_first_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
@@ -40,6 +41,12 @@ _lib.lib.noise_pw_bwd_max_rows.argtypes = [ctypes.c_int, ctypes.c_int]
 
 def pw_bwd_max_rows(Cout, Cin):
     return _lib.lib.noise_pw_bwd_max_rows(Cout, Cin)
+
+class FoldJob(ctypes.Structure):
+    """noise_fold_job of include/noise_hip.h"""
+    _fields_ = [("slab", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int), ("ncols", ctypes.c_int),
+                ("row_stride", ctypes.c_int), ("tr_k", ctypes.c_int), ("tr_C", ctypes.c_int)]
+
 
 NONE = (None, None, 0)
 
