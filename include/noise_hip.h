@@ -163,7 +163,9 @@ int noise_attn_post_fwd(const float* o, const float* xhat0, const float* ln0_w, 
                         const float* b2, const float* ln2_w, const float* ln2_b, const float* vad_w,
                         const float* vad_b, float* xhat1, float* rstd1, float* hdn, float* xhat2, float* rstd2,
                         float* x3, float* vad, long ntok, int n, int d_model, int heads, int dk, void* stream);
-/* grads = [dW2|dW1|dWfc|dln2_w|dln2_b|db2|db1|dln1_w|dln1_b|dvad_w|dvad_b]; scratch: noise_attn_max_blocks() rows */
+/* grads = [dW2|dW1|dWfc|dln2_w|dln2_b|db2|db1|dln1_w|dln1_b|dvad_w|dvad_b]; scratch: noise_attn_max_blocks() rows.
+ * grads = NULL (here and in noise_attn_pre_bwd) leaves the min(ceil(ntok/64), noise_attn_max_blocks()) slab rows of
+ * that layout unfolded in scratch for noise_fold_jobs. */
 int noise_attn_post_bwd(const float* g3, const float* d_vad, const float* o, const float* xhat1, const float* rstd1,
                         const float* hdn, const float* xhat2, const float* rstd2, const float* x3, const float* fc,
                         const float* ln1_w, const float* ln1_b, const float* w1, const float* w2, const float* ln2_w,

@@ -1172,7 +1172,7 @@ NOISE_EXPORT int noise_attn_post_bwd(const float* g3, const float* d_vad, const 
                                      int dk, void* stream) {
   if (check_attn("noise_attn_post_bwd", ntok, n, d_model, heads, dk)) return -1;
   NOISE_REQUIRE(g3 && d_vad && o && xhat1 && rstd1 && hdn && xhat2 && rstd2 && x3 && fc && ln1_w && ln1_b && w1 && w2 &&
-                    ln2_w && vad_w && d_o && d_x1 && grads && scratch,
+                    ln2_w && vad_w && d_o && d_x1 && scratch,
                 "noise_attn_post_bwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   PostParams P{fc, ln1_w, ln1_b, w1, nullptr, w2, nullptr, ln2_w, nullptr, vad_w, nullptr};
@@ -1184,8 +1184,10 @@ NOISE_EXPORT int noise_attn_post_bwd(const float* g3, const float* d_vad, const 
   hipLaunchKernelGGL(attn_post_bwd_kernel, dim3(grid), dim3(256), smem, st, g3, d_vad, o, xhat1, rstd1, hdn, xhat2, rstd2, x3,
                      P, d_o, d_x1, scratch, d);
   NOISE_CHECK_LAUNCH("noise_attn_post_bwd");
-  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, SLAB_COLS)), dim3(256), 0, st, scratch, grid, ncols, grads);
-  NOISE_CHECK_LAUNCH("noise_attn_post_bwd/reduce");
+  if (grads != nullptr) {   // NULL: the caller folds the slab rows (min(ceil(ntok/64), noise_attn_max_blocks())) itself
+    hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, SLAB_COLS)), dim3(256), 0, st, scratch, grid, ncols, grads);
+    NOISE_CHECK_LAUNCH("noise_attn_post_bwd/reduce");
+  }
   return 0;
 }
 
@@ -1195,7 +1197,7 @@ NOISE_EXPORT int noise_attn_pre_bwd(const float* d_qkv, const float* d_x1, const
                                     const float* wv, float* d_x0, float* grads, float* scratch, long ntok, int n,
                                     int d_model, int heads, int dk, void* stream) {
   if (check_attn("noise_attn_pre_bwd", ntok, n, d_model, heads, dk)) return -1;
-  NOISE_REQUIRE(d_qkv && d_x1 && xhat0 && rstd0 && ln_w && ln_b && wq && wk && wv && d_x0 && grads && scratch,
+  NOISE_REQUIRE(d_qkv && d_x1 && xhat0 && rstd0 && ln_w && ln_b && wq && wk && wv && d_x0 && scratch,
                 "noise_attn_pre_bwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   const int O = 3 * d.hd;
@@ -1208,7 +1210,9 @@ NOISE_EXPORT int noise_attn_pre_bwd(const float* d_qkv, const float* d_x1, const
   hipLaunchKernelGGL(attn_pre_bwd_kernel, dim3(grid), dim3(256), smem, st, d_qkv, d_x1, xhat0, rstd0, ln_w, ln_b, wq, wk, wv,
                      d_x0, scratch, d);
   NOISE_CHECK_LAUNCH("noise_attn_pre_bwd");
-  hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, SLAB_COLS)), dim3(256), 0, st, scratch, grid, ncols, grads);
-  NOISE_CHECK_LAUNCH("noise_attn_pre_bwd/reduce");
+  if (grads != nullptr) {   // NULL: the caller folds the slab rows (min(ceil(ntok/64), noise_attn_max_blocks())) itself
+    hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(noise_cdiv(ncols, SLAB_COLS)), dim3(256), 0, st, scratch, grid, ncols, grads);
+    NOISE_CHECK_LAUNCH("noise_attn_pre_bwd/reduce");
+  }
   return 0;
 }

@@ -170,6 +170,9 @@ class DenoiserPlan:
         self.slab = torch.empty(max(ops.CONV_MAX_BLOCKS * 12 * maxC, maxw, ATTN_MAX_BLOCKS * att_cols), **f32)
         self.slab2 = torch.empty(1024 * 2 * maxC, **f32)
         self.att_grads = torch.empty(att_cols, **f32)
+        # per-workgroup weight-gradient rows of the two attention backward kernels (folded with the other layers')
+        self.att_slab_post = torch.empty(ATTN_MAX_BLOCKS * (2 * D * D + D * hd + 7 * D + 1), **f32)
+        self.att_slab_pre = torch.empty(ATTN_MAX_BLOCKS * (3 * hd * D + 2 * D), **f32)
         self.bwd_ready = False
 
     # -------------------------------------------------------------------------------- backward buffers
@@ -333,29 +336,30 @@ class DenoiserPlan:
         st = _lib.stream()
         dims = (self.ntok, self.n_tok, self.d_model, net.n_head, net.d_k)
         D, hd = self.d_model, self.hd
+        att_rows = min(-(-self.ntok // 64), ATTN_MAX_BLOCKS)
+        post_stride, pre_stride = 2 * D * D + D * hd + 7 * D + 1, 3 * hd * D + 2 * D
         _lib.call("noise_attn_post_bwd", ptr(g3), ptr(d_vad), ptr(self.att_o), ptr(self.xhat1), ptr(self.rstd1),
                   ptr(self.hdn), ptr(self.xhat2), ptr(self.rstd2), ptr(self.x3), ptr(sa.fc.weight),
                   ptr(sa.layer_norm.weight), ptr(sa.layer_norm.bias), ptr(ff.w_1.weight), ptr(ff.w_2.weight),
-                  ptr(ff.layer_norm.weight), ptr(net.vad.weight), ptr(self.d_o), ptr(self.d_x1), ptr(self.att_grads),
-                  ptr(self.slab), *dims, st, nbytes=4 * self.ntok * (2 * self.hd + 7 * self.d_model))
-        g = self.att_grads
+                  ptr(ff.layer_norm.weight), ptr(net.vad.weight), ptr(self.d_o), ptr(self.d_x1), None,
+                  ptr(self.att_slab_post), *dims, st, nbytes=4 * self.ntok * (2 * self.hd + 7 * self.d_model))
         o = 0
         for t, n in ((ff.w_2.weight, D * D), (ff.w_1.weight, D * D), (sa.fc.weight, D * hd), (ff.layer_norm.weight, D),
                      (ff.layer_norm.bias, D), (ff.w_2.bias, D), (ff.w_1.bias, D), (sa.layer_norm.weight, D),
                      (sa.layer_norm.bias, D), (net.vad.weight, D), (net.vad.bias, 1)):
-            G(t).view(-1).copy_(g[o:o + n])
+            fold.append((self.att_slab_post[o:], G(t).view(-1), att_rows, n, post_stride, 0, 0))
             o += n
         _lib.call("noise_attn_core_bwd", ptr(self.qkv), ptr(self.d_o), ptr(self.ml), ptr(self.keep), self.seed,
                   float(self.p_drop if self.keep is None else ATTN_DROPOUT), ptr(self.d_qkv), *dims, st,
                   nbytes=4 * self.ntok * 7 * self.hd)
         _lib.call("noise_attn_pre_bwd", ptr(self.d_qkv), ptr(self.d_x1), ptr(self.xhat0), ptr(self.rstd0),
                   ptr(att.layer_norm.weight), ptr(att.layer_norm.bias), ptr(sa.w_qs.weight), ptr(sa.w_ks.weight),
-                  ptr(sa.w_vs.weight), ptr(self.d_x0), ptr(self.att_grads), ptr(self.slab), *dims, st,
+                  ptr(sa.w_vs.weight), ptr(self.d_x0), None, ptr(self.att_slab_pre), *dims, st,
                   nbytes=4 * self.ntok * (3 * self.hd + 3 * self.d_model))
         o = 0
         for t, n in ((sa.w_qs.weight, hd * D), (sa.w_ks.weight, hd * D), (sa.w_vs.weight, hd * D),
                      (att.layer_norm.weight, D), (att.layer_norm.bias, D)):
-            G(t).view(-1).copy_(g[o:o + n])
+            fold.append((self.att_slab_pre[o:], G(t).view(-1), att_rows, n, pre_stride, 0, 0))
             o += n
         # the bottleneck tensor gets dL/dx0 from the attention block plus the skip gradient of decoder.0: this one
         # BatchNorm backward keeps its own (small) reduction pass
