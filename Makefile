@@ -10,7 +10,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -fvisibility=hidden -Wal
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/lazy.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/noise_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
