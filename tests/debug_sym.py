@@ -1,8 +1,10 @@
-"""Compare a fused training step with the folded STFT kernels against the general ones (same weights, same batch)."""
+"""(diagnostic, not collected by pytest; lives under tests/ because it checks against the CPU oracle)
+Compare a fused training step with the folded STFT kernels against the general ones (same weights, same batch)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_model as T
 dev = torch.device("cuda:0")
 gd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
