@@ -6,3 +6,4 @@ from .mixer import segmental_snr_mixer, activitydetector  # noqa: F401
 from .models import VADSpectralV2, VADMobileNetV2  # noqa: F401
 from .optim import FusedAdamW  # noqa: F401
 from .data import VADNoiseDataModule  # noqa: F401
+from .streaming import StreamingDenoiser  # noqa: F401

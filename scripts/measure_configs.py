@@ -51,6 +51,26 @@ for N in (1, 1024):
     assert torch.equal(ref, got), "graph replay differs from the eager forward"
     dt = timed(lambda: run(x.view(N, 1, 1, -1)), reps=50)
     out[f"window_forward_A_N{N}_hipgraph"] = {"ms_per_step": round(1000 * dt, 3), "audio_s_per_s": round(N * 0.2 / dt, 1)}
+# streaming driver (worker.js protocol, 0.2 s of new audio per stream and hop): latency per hop at N = 1 over 1000 hops
+# (host-synchronised, HIP-graph replay) and throughput at N = 1024
+from noise_amd import StreamingDenoiser
+import time as _time
+for N in (1, 1024):
+    sdrv = StreamingDenoiser(m, N)
+    blk = synth_batch(N, 3200, dev, seed=10)[0].view(N, 3200)
+    for _ in range(5):
+        sdrv.push_block(blk)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(1000 if N == 1 else 50):
+        t0 = _time.perf_counter()
+        sdrv.push_block(blk)
+        torch.cuda.synchronize()
+        lat.append(_time.perf_counter() - t0)
+    lat.sort()
+    p50, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.99) - 1]
+    out[f"stream_driver_A_N{N}"] = {"hop_ms_p50": round(1000 * p50, 3), "hop_ms_p99": round(1000 * p99, 3),
+                                    "audio_s_per_s": round(N * 0.2 / p50, 1)}
 # mixing: U utterances of 10 s, float64
 U, L = 1024, 160000
 g = torch.Generator(device="cpu").manual_seed(3)
