@@ -96,9 +96,10 @@ int noise_dw3x3_bwd(const float* dz, const float* y_out, const float* coef3, con
 int noise_first_conv_fwd(const float* logmag, const float* absmax, const float* w, float* out, float* stats_slab,
                          int* slab_rows, int B, int H, int W, int hp, int wp, float pad_value, int C, int sy,
                          int sx, void* stream);
+/* w (optional): with the layer's weights the stride-2 path rebuilds y_out from the input instead of reading it */
 int noise_first_conv_wgrad(const float* dz, const float* y_out, const float* coef3, const float* logmag,
-                           const float* absmax, float* dw, float* scratch, int B, int H, int W, int hp, int wp,
-                           float pad_value, int C, int sy, int sx, void* stream);
+                           const float* absmax, const float* w, float* dw, float* scratch, int B, int H, int W,
+                           int hp, int wp, float pad_value, int C, int sy, int sx, void* stream);
 /* last ConvTranspose2d C->1 with bias (models.py:1164-1171) fused with crop (:610) and the additive mask
  * enh = clamp(logmag/max + filt, -1, 1)*max (:762-763); either of enh / filt may be NULL */
 int noise_last_convT_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,

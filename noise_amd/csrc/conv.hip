@@ -695,10 +695,11 @@ NOISE_EXPORT int noise_first_conv_fwd(const float* logmag, const float* absmax, 
 }
 
 NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, const float* coef3, const float* logmag,
-                                        const float* absmax, float* dw, float* scratch, int B, int H, int W, int hp,
-                                        int wp, float pad_value, int C, int sy, int sx, void* stream) {
+                                        const float* absmax, const float* w, float* dw, float* scratch, int B, int H,
+                                        int W, int hp, int wp, float pad_value, int C, int sy, int sx, void* stream) {
   if (check_c("noise_first_conv_wgrad", C)) return -1;
   NOISE_REQUIRE(dz && logmag && absmax && dw && scratch, "noise_first_conv_wgrad: null pointer");
+  NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr || w != nullptr, "noise_first_conv_wgrad: coef3 needs y_out or w");
   FirstDims d{B, H, W, hp, wp, (H + hp - 1) / sy + 1, (W + wp - 1) / sx + 1, C, sy, sx, pad_value};
   LazyGrad G{dz, y_out, coef3};
   int grid = conv_grid((long)B * d.Ho * d.Wo, C);
@@ -708,12 +709,17 @@ NOISE_EXPORT int noise_first_conv_wgrad(const float* dz, const float* y_out, con
     FirstWalkDims wd{B, H, W, hp, wp, d.Ho, d.Wo, C, pad_value, 0, 0, 0};
     first_walk_plan(wd, BWD_MAX_BLOCKS, grid);
     const int CG = C / 4;
-    if (CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64)
-      NOISE_LAUNCH_ROUNDS(first_walk_wgrad_kernel<true>, grid, (size_t)PPB * 9 * C * sizeof(float), st, G,
-                         logmag, absmax, scratch, wd);
+    const bool coop = CG >= 8 && (CG & (CG - 1)) == 0 && CG <= 64;
+    const bool recomp = coef3 != nullptr && w != nullptr;   // with the weights at hand y_out is rebuilt, not read
+    const size_t sm = (size_t)PPB * 9 * C * sizeof(float);
+    if (coop && recomp)
+      NOISE_LAUNCH_ROUNDS((first_walk_wgrad_kernel<true, true>), grid, sm, st, G, logmag, absmax, w, scratch, wd);
+    else if (coop)
+      NOISE_LAUNCH_ROUNDS((first_walk_wgrad_kernel<true, false>), grid, sm, st, G, logmag, absmax, w, scratch, wd);
+    else if (recomp)
+      NOISE_LAUNCH_ROUNDS((first_walk_wgrad_kernel<false, true>), grid, sm, st, G, logmag, absmax, w, scratch, wd);
     else
-      NOISE_LAUNCH_ROUNDS(first_walk_wgrad_kernel<false>, grid, (size_t)PPB * 9 * C * sizeof(float), st, G,
-                         logmag, absmax, scratch, wd);
+      NOISE_LAUNCH_ROUNDS((first_walk_wgrad_kernel<false, false>), grid, sm, st, G, logmag, absmax, w, scratch, wd);
   } else {
     hipLaunchKernelGGL(first_conv_wgrad_kernel, dim3(grid), dim3(256), (size_t)PPB * 9 * C * sizeof(float), st, G, logmag,
                        absmax, scratch, d);

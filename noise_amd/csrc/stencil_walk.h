@@ -894,9 +894,12 @@ __global__ __launch_bounds__(256) void first_walk_fwd_kernel(const float* __rest
 }
 
 // dW[c][k] = sum_o dy[o][c] * x_in(2o - 1 + k)   (the input is data: no input gradient)
-template <bool COOP>
+// RECOMP: the layer's raw output y, which the lazy BatchNorm backward needs, is rebuilt from the input window the
+// thread holds anyway (9 multiply-adds per channel) instead of being read back (C floats per pixel).
+template <bool COOP, bool RECOMP>
 __global__ __launch_bounds__(256) void first_walk_wgrad_kernel(LazyGrad G, const float* __restrict__ x,
                                                                const float* __restrict__ absmax,
+                                                               const float* __restrict__ w,
                                                                float* __restrict__ dw_slab, FirstWalkDims d) {
   extern __shared__ float red[];
   const int C = d.C, CG = C >> 2, PPB = 256 / CG;
@@ -906,6 +909,8 @@ __global__ __launch_bounds__(256) void first_walk_wgrad_kernel(LazyGrad G, const
   for (int k = 0; k < 9; ++k) dwk[k] = f4(0.f);
   if (pl < PPB) {
     const LazyGrad4 gr = lazygrad4_init(G, C, c);
+    float4 wk[9];
+    if (RECOMP) load_taps(w, c, false, wk);
     for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
       const int slot = g * PPB + pl;
       if (slot >= d.B * d.nb * d.Wo) continue;
@@ -918,9 +923,44 @@ __global__ __launch_bounds__(256) void first_walk_wgrad_kernel(LazyGrad G, const
       float t0[3], t1[3], t2[3];
       win.row(2 * r0 - 1, t0);
       size_t off = (((size_t)bi * d.Ho + r0) * d.Wo + ox) * C + c;
-      for (int oy = r0; oy < r1; ++oy, off += (size_t)d.Wo * C) {
-        win.template rows2<COOP>(2 * oy, cg, CG, t1, t2);
-        const float4 dy = lazygrad4_at(gr, off);
+      const size_t orow = (size_t)d.Wo * C;
+      // software pipeline: the window element this lane contributes to the NEXT step and the next gradient row are
+      // requested before the arithmetic of the current step
+      const int e = cg < 6 ? cg : 0;
+      float mine = COOP ? win.at(2 * r0 + e / 3, e % 3) : 0.f;
+      float4 nz = ld4(gr.dz + off), ny = RECOMP ? f4(0.f) : ld4(gr.y + off);   // gr.y aliases dz without a BatchNorm
+      for (int oy = r0; oy < r1; ++oy, off += orow) {
+        if (COOP) {
+          const int base = (int)(threadIdx.x & 63) & ~(CG - 1);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            t1[j] = __shfl(mine, base + j, 64);
+            t2[j] = __shfl(mine, base + 3 + j, 64);
+          }
+        } else {
+          win.row(2 * oy, t1);
+          win.row(2 * oy + 1, t2);
+        }
+        const float4 cz = nz, cy = ny;
+        const size_t noff = oy + 1 < r1 ? off + orow : off;
+        if (COOP) mine = win.at(2 * (oy + 1) + e / 3, e % 3);
+        nz = ld4(gr.dz + noff);
+        if (!RECOMP) ny = ld4(gr.y + noff);
+        __builtin_amdgcn_sched_barrier(0);
+        float4 dy;
+        if (RECOMP) {
+          float4 y = f4(t0[0]) * wk[0];
+#pragma unroll
+          for (int j = 1; j < 3; ++j) y = fma4(f4(t0[j]), wk[j], y);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            y = fma4(f4(t1[j]), wk[3 + j], y);
+            y = fma4(f4(t2[j]), wk[6 + j], y);
+          }
+          dy = lazygrad4_eval(gr, cz, y);
+        } else {
+          dy = lazygrad4_eval(gr, cz, cy);
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           dwk[j] = fma4(dy, f4(t0[j]), dwk[j]);

@@ -375,7 +375,7 @@ class DenoiserPlan:
                 layer_backward(r)
         r0 = self.enc[0][0]
         ops.first_conv_wgrad((r0.dz, r0.y, r0.coef3), self.logmag, self.absmax, G(r0.conv.weight), self.slab, self.B,
-                             self.H, self.W, self.hp, self.wp, net.pad_value, r0.C, r0.stride)
+                             self.H, self.W, self.hp, self.wp, net.pad_value, r0.C, r0.stride, w=r0.conv.weight)
         assert not pending_skip, "unconsumed skip gradients"
         self._fold_weight_grads(fold)
 

@@ -19,7 +19,7 @@ _lib.register({
     "noise_dw3x3_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_dw3x3_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_first_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
-    "noise_first_conv_wgrad": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "noise_first_conv_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "noise_last_convT_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_last_convT_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_bn_finalize_fwd": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _F, _F, _P, _P],
@@ -100,11 +100,13 @@ def first_conv_fwd(logmag, absmax, w, out, slab, B, H, W, hp, wp, pad_value, C, 
     return rows.value
 
 
-def first_conv_wgrad(grad, logmag, absmax, dw, scratch, B, H, W, hp, wp, pad_value, C, stride):
+def first_conv_wgrad(grad, logmag, absmax, dw, scratch, B, H, W, hp, wp, pad_value, C, stride, w=None):
+    """w: the layer's weights; with them the stride-2 kernel rebuilds the raw output instead of reading grad's y."""
     dz, y, coef3 = grad
-    _lib.call("noise_first_conv_wgrad", ptr(dz), ptr(y), ptr(coef3), ptr(logmag), ptr(absmax), ptr(dw), ptr(scratch),
-              B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream(),
-              nbytes=4 * (B * H * W + dz.numel() * (2 if coef3 is not None else 1)))
+    reads_y = coef3 is not None and not (w is not None and tuple(stride) == (2, 2))
+    _lib.call("noise_first_conv_wgrad", ptr(dz), ptr(y), ptr(coef3), ptr(logmag), ptr(absmax), ptr(w), ptr(dw),
+              ptr(scratch), B, H, W, hp, wp, float(pad_value), C, stride[0], stride[1], _lib.stream(),
+              nbytes=4 * (B * H * W + dz.numel() * (2 if reads_y else 1)))
 
 
 def last_convT_fwd(a, b, w, bias, logmag, absmax, enh, filt, B, Hi, Wi, C, stride, H, W):
