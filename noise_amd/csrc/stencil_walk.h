@@ -868,8 +868,23 @@ __global__ __launch_bounds__(256) void first_walk_fwd_kernel(const float* __rest
       float t0[3], t1[3], t2[3];
       win.row(2 * r0 - 1, t0);
       float* o = out + (((size_t)bi * d.Ho + r0) * d.Wo + ox) * C + c;
+      // the window element this lane contributes to the NEXT step is requested before this step's arithmetic
+      const int e = cg < 6 ? cg : 0;
+      float mine = COOP ? win.at(2 * r0 + e / 3, e % 3) : 0.f;
       for (int oy = r0; oy < r1; ++oy, o += (size_t)d.Wo * C) {
-        win.template rows2<COOP>(2 * oy, cg, CG, t1, t2);
+        if (COOP) {
+          const int base = (int)(threadIdx.x & 63) & ~(CG - 1);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            t1[j] = __shfl(mine, base + j, 64);
+            t2[j] = __shfl(mine, base + 3 + j, 64);
+          }
+          mine = win.at(2 * (oy + 1) + e / 3, e % 3);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          win.row(2 * oy, t1);
+          win.row(2 * oy + 1, t2);
+        }
         float4 acc = f4(t0[0]) * wk[0];
         acc = fma4(f4(t0[1]), wk[1], acc);
         acc = fma4(f4(t0[2]), wk[2], acc);
