@@ -432,14 +432,14 @@ __device__ __forceinline__ void stage_head(float* dst, const float* __restrict__
     }
     return;
   }
+  // any d_k (the reference's 64 // 6 = 10): scalar loads from clamped addresses, padding selected afterwards, so the
+  // loads of several trips are in flight together
+#pragma unroll 4
   for (int i = threadIdx.x; i < n * DKP; i += AW) {
     const int j = i / DKP, c = i - j * DKP;
-    float v = 0.f;
-    if (c < dk) {
-      v = src[(base + j) * ld + col0 + c];
-      if (scale_div != 0.f) v = v / scale_div;
-    }
-    dst[i] = v;
+    float v = src[(base + j) * ld + col0 + (c < dk ? c : dk - 1)];
+    if (scale_div != 0.f) v = v / scale_div;
+    dst[i] = c < dk ? v : 0.f;
   }
 }
 
@@ -479,7 +479,10 @@ __global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __r
   const float inv_keep = 1.f / (1.f - p_drop);
   float q[DKP];
 #pragma unroll
-  for (int c = 0; c < DKP; ++c) q[c] = c < dk ? qkv[(base + i) * O + h * dk + c] / temp : 0.f;
+  for (int c = 0; c < DKP; ++c) {
+    const float v = qkv[(base + i) * O + h * dk + (c < dk ? c : dk - 1)] / temp;   // clamped, then selected: no branch
+    q[c] = c < dk ? v : 0.f;
+  }
   float s[AW];
   float m = -INFINITY;
 #pragma unroll
