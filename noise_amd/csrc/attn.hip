@@ -621,11 +621,14 @@ __global__ __launch_bounds__(256) void attn_core_fwd_mfma_kernel(const float* __
   float* ks = lds;                   // [n16][DKP], rows >= n zero
   float* vs = ks + n16 * DKP;        // [n16 + 1][DKP] (one spare row: lanes d >= DKP read past a row)
   const long base = (long)b * n;
-  for (int i = threadIdx.x; i < (n16 + 1) * DKP; i += 256) {
+#pragma unroll 4
+  for (int i = threadIdx.x; i < (n16 + 1) * DKP; i += 256) {   // clamped addresses, padding selected afterwards
     const int j = i / DKP, c = i - j * DKP;
     const bool in = j < n && c < dk;
-    if (j < n16) ks[i] = in ? qkv[(base + j) * O + d.hd + h * dk + c] : 0.f;
-    vs[i] = in ? qkv[(base + j) * O + 2 * d.hd + h * dk + c] : 0.f;
+    const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : dk - 1);
+    const float kv = row[d.hd], vv = row[2 * d.hd];
+    if (j < n16) ks[i] = in ? kv : 0.f;
+    vs[i] = in ? vv : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
