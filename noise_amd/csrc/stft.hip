@@ -326,23 +326,28 @@ __global__ __launch_bounds__(64 * STFT_SYM_MAX_WAVES) void stft_frames_sym_kerne
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int t = t0 + 32 * c + n;
-      if (t >= d.T) continue;
+      const bool tin = t < d.T;
+      const int tc = tin ? t : d.T - 1;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int f = 32 * ft + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (f >= d.F) continue;
+        const bool in = tin && f < d.F;
         const float re = acc[r][0][c][e], im = acc[r][1][c][e];
-        const size_t o = ((size_t)b * d.F + f) * d.T + t;
+        // clamped address: the loads of the gradient path need no branch, only the stores are conditional
+        const size_t o = ((size_t)b * d.F + (f < d.F ? f : d.F - 1)) * d.T + tc;
         if (MODE == 0) {
           const float lm = logf(fmaxf(sqrtf(re * re + im * im), 1e-3f));
-          out0[o] = lm;
-          if (out1 != nullptr) out1[o] = atan2f(im, re);
-          amax = fmaxf(amax, fabsf(lm));
+          if (in) {
+            out0[o] = lm;
+            if (out1 != nullptr) out1[o] = atan2f(im, re);
+            amax = fmaxf(amax, fabsf(lm));
+          }
         } else {
           float sn, cs;
           sincosf(phase[o], &sn, &cs);
           const float gv = expf(logmag[o]) * (cs * re + sn * im);
-          out0[o] = d.accum ? out0[o] + gv : gv;
+          const float prev = d.accum ? out0[o] : 0.f;
+          if (in) out0[o] = prev + gv;
         }
       }
     }
@@ -371,19 +376,16 @@ __global__ __launch_bounds__(64 * STFT_SYM_MAX_WAVES) void istft_sym_kernel(
   const int tstart = q0 - (R - 1);
 
   // z rows 2f (mag*cos), 2f+1 (mag*sin); row pair F is zero (odd F: the k-loop pairs bins two by two)
-  for (int i = tid; i < (F + 1) * 32; i += nthr) {
+#pragma unroll 2
+  for (int i = tid; i < (F + 1) * 32; i += nthr) {   // clamped addresses, zero selected afterwards: no branch around loads
     const int f = i >> 5, tl = i & 31, t = tstart + tl;
-    float zr = 0.f, zi = 0.f;
-    if (f < F && t >= 0 && t < d.T) {
-      const size_t o = ((size_t)b * F + f) * d.T + t;
-      const float m = expf(logmag[o]);
-      float sn, cs;
-      sincosf(phase[o], &sn, &cs);
-      zr = m * cs;
-      zi = m * sn;
-    }
-    lds[(2 * f) * 32 + tl] = zr;
-    lds[(2 * f + 1) * 32 + tl] = zi;
+    const bool in = f < F && t >= 0 && t < d.T;
+    const size_t o = ((size_t)b * F + (f < F ? f : F - 1)) * d.T + (t < 0 ? 0 : (t < d.T ? t : d.T - 1));
+    const float m = expf(logmag[o]);
+    float sn, cs;
+    sincosf(phase[o], &sn, &cs);
+    lds[(2 * f) * 32 + tl] = in ? m * cs : 0.f;
+    lds[(2 * f + 1) * 32 + tl] = in ? m * sn : 0.f;
   }
   __syncthreads();
 
