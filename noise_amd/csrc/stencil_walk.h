@@ -598,8 +598,13 @@ __global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc B
     float4 s00, s01, s10, s11;
     load_row(m0, s00, s01);
     const int X = 2 * mx + q - d.ox0;
+    const int Xc = X < 0 ? 0 : (X < d.W ? X : d.W - 1);
     for (int m = m0; m < m0 + d.bh; ++m) {
       load_row(m + 1, s10, s11);
+      // the log-magnitude this lane may need at the end of the step is requested now, from a clamped address
+      const int Y = 2 * m + p - d.oy0;
+      const size_t oc = ((size_t)bi * d.H + (Y < 0 ? 0 : (Y < d.H ? Y : d.H - 1))) * d.W + Xc;
+      const float lmv = enh ? logmag[oc] : 0.f;
       float4 t00 = s00 * wk[4];
       float4 t01 = fma4(s01, wk[3], s00 * wk[5]);
       float4 t10 = fma4(s10, wk[1], s00 * wk[7]);
@@ -616,13 +621,11 @@ __global__ __launch_bounds__(256) void last_cell_fwd_kernel(LazySrc A, LazySrc B
         p11 += __shfl_xor(p11, o, 64);
       }
       const float f = (p ? (q ? p11 : p10) : (q ? p01 : p00)) + bv;
-      const int Y = 2 * m + p - d.oy0;
       if (cg < 4 && m < m1 && Y >= 0 && Y < d.H && X >= 0 && X < d.W) {
-        const size_t o = ((size_t)bi * d.H + Y) * d.W + X;
-        if (filt_out) filt_out[o] = f;
+        if (filt_out) filt_out[oc] = f;
         if (enh) {
-          const float v = logmag[o] / mxv + f;
-          enh[o] = fminf(fmaxf(v, -1.f), 1.f) * mxv;
+          const float v = lmv / mxv + f;
+          enh[oc] = fminf(fmaxf(v, -1.f), 1.f) * mxv;
         }
       }
       s00 = s10;
