@@ -458,7 +458,16 @@ __device__ __forceinline__ void store_head_row(float* dst, const float (&v)[DK4 
     if (c < dk) dst[c] = div != 0.f ? v[c] / div : v[c];
 }
 
-template <int DK4>
+// DROP: 0 = no dropout, 1 = explicit keep mask, 2 = counter-based RNG.  A compile-time mode keeps the per-weight code
+// of the wave kernels free of the run-time tests in keep_elem.
+template <int DROP>
+__device__ __forceinline__ bool keep_at(const unsigned char* keep, unsigned long long seed, float p_drop, long idx) {
+  if (DROP == 0) return true;
+  if (DROP == 1) return keep[idx] != 0;
+  return keep_elem(nullptr, seed, p_drop, idx);
+}
+
+template <int DK4, int DROP>
 __global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                 float* __restrict__ ml,
                                                                 const unsigned char* __restrict__ keep,
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __r
     if (j < n) {
       const float e = expf(s[j] - m);
       l += e;
-      if (keep_elem(keep, seed, p_drop, mrow + j)) axpy_row<DK4>(e, vs + j * DKP, acc);
+      if (keep_at<DROP>(keep, seed, p_drop, mrow + j)) axpy_row<DK4>(e, vs + j * DKP, acc);
     }
   }
   const float sc = inv_keep / l;
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __r
   }
 }
 
-template <int DK4>
+template <int DK4, int DROP>
 __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                 const float* __restrict__ ml,
                                                                 const unsigned char* __restrict__ keep,
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
   for (int j = 0; j < AW; ++j) {
     if (j < n) {
       const float sj = dot_row<DK4>(q, ks + j * DKP);
-      const bool kp = keep_elem(keep, seed, p_drop, mrow + j);
+      const bool kp = keep_at<DROP>(keep, seed, p_drop, mrow + j);
       const float dp = kp ? dot_row<DK4>(dout, vs + j * DKP) : 0.f;
       pr[j] = expf(sj - mi) * li;
       Di = fmaf(pr[j], dp * inv_keep, Di);
@@ -1082,10 +1091,19 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
     const int dk4 = (dk + 3) / 4;
     const size_t sm = (size_t)2 * n * dk4 * 4 * sizeof(float);
     const dim3 grid((unsigned)(ntok / n) * heads);
+    const int drop = keep ? 1 : (p_drop > 0.f ? 2 : 0);
 #define X(K4)                                                                                                     \
-  if (dk4 == K4)                                                                                                  \
-    hipLaunchKernelGGL(attn_core_fwd_wave_kernel<K4>, grid, dim3(AW), sm, (hipStream_t)stream, qkv, o, ml, keep, seed, \
-                       p_drop, d);
+  if (dk4 == K4) {                                                                                                \
+    if (drop == 0)                                                                                                \
+      hipLaunchKernelGGL((attn_core_fwd_wave_kernel<K4, 0>), grid, dim3(AW), sm, (hipStream_t)stream, qkv, o, ml, keep, \
+                         seed, p_drop, d);                                                                        \
+    else if (drop == 1)                                                                                           \
+      hipLaunchKernelGGL((attn_core_fwd_wave_kernel<K4, 1>), grid, dim3(AW), sm, (hipStream_t)stream, qkv, o, ml, keep, \
+                         seed, p_drop, d);                                                                        \
+    else                                                                                                          \
+      hipLaunchKernelGGL((attn_core_fwd_wave_kernel<K4, 2>), grid, dim3(AW), sm, (hipStream_t)stream, qkv, o, ml, keep, \
+                         seed, p_drop, d);                                                                        \
+  }
     X(1) X(2) X(3) X(4)
 #undef X
     NOISE_CHECK_LAUNCH("noise_attn_core_fwd/wave");
@@ -1130,10 +1148,19 @@ NOISE_EXPORT int noise_attn_core_bwd(const float* qkv, const float* d_o, const f
     const int dk4 = (dk + 3) / 4;
     const size_t sm = (size_t)(4 * n * dk4 * 4 + n * (n | 1)) * sizeof(float);
     const dim3 grid((unsigned)(ntok / n) * heads);
+    const int drop = keep ? 1 : (p_drop > 0.f ? 2 : 0);
 #define X(K4)                                                                                                        \
-  if (dk4 == K4)                                                                                                     \
-    hipLaunchKernelGGL(attn_core_bwd_wave_kernel<K4>, grid, dim3(AW), sm, (hipStream_t)stream, qkv, d_o, ml, keep, seed, \
-                       p_drop, d_qkv, d);
+  if (dk4 == K4) {                                                                                                   \
+    if (drop == 0)                                                                                                   \
+      hipLaunchKernelGGL((attn_core_bwd_wave_kernel<K4, 0>), grid, dim3(AW), sm, (hipStream_t)stream, qkv, d_o, ml, keep, \
+                         seed, p_drop, d_qkv, d);                                                                    \
+    else if (drop == 1)                                                                                              \
+      hipLaunchKernelGGL((attn_core_bwd_wave_kernel<K4, 1>), grid, dim3(AW), sm, (hipStream_t)stream, qkv, d_o, ml, keep, \
+                         seed, p_drop, d_qkv, d);                                                                    \
+    else                                                                                                             \
+      hipLaunchKernelGGL((attn_core_bwd_wave_kernel<K4, 2>), grid, dim3(AW), sm, (hipStream_t)stream, qkv, d_o, ml, keep, \
+                         seed, p_drop, d_qkv, d);                                                                    \
+  }
     X(1) X(2) X(3) X(4)
 #undef X
     NOISE_CHECK_LAUNCH("noise_attn_core_bwd/wave");
