@@ -755,9 +755,6 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
   if ((size_t)Cout * Cin * sizeof(float) > smem) smem = (size_t)Cout * Cin * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   bool done = false;
-  // NOISE_PW_NO_RECOMPUTE (diagnostic): always read the layer's raw output back
-  static const bool recompute_off = getenv("NOISE_PW_NO_RECOMPUTE") != nullptr;
-  const bool recompute = coef3 != nullptr && !recompute_off;
 #define X(nt, mt)                                                                                                      \
   if constexpr (mt * nt <= 48) {                                                                                       \
     if (!done && MT == mt && NT == nt) {                                                                               \
