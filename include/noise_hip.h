@@ -112,6 +112,10 @@ int noise_last_convT_bwd(const float* d_enh, const float* enh, const float* absm
                          const float* w, float* g_in, float* dw, float* dbias, float* scratch, const float* g_other,
                          const float* epi_coef, int epi_relu6, int* slab_rows, int B, int Hi, int Wi, int C, int sy,
                          int sx, int H, int W, void* stream);
+/* crop-from-the-end of a skip tensor before the decoder add (models.py:608, `skip[..., -h:, -w:]`):
+ * dst [B][Hd][Wd][C] = src [B][Hs][Ws][C] at rows oy.., columns ox.. (raw values; the lazy coefficients carry over) */
+int noise_crop_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int C, int oy, int ox, int Hd, int Wd,
+                    void* stream);
 /* pointwise convs (models.py:371-381, :395-396) as fp32 MFMA products: out [npix][N] = a [npix][K] x W[N][K]^T */
 int noise_pw_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
                  int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, long npix, int K, int N,

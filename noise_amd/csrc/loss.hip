@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void vad_label_kernel(const float* __restrict_
 // Cross-pair waveform L1.  One workgroup = WT consecutive time samples of every clip.
 //   pair_abs partial, and sgn[i][t] = sum_j sign(w_i[t] - c_j[t])
 constexpr int WT = 16;     // time samples per workgroup
-constexpr int WJ = 1024;   // clean rows staged per LDS fill
+constexpr int WJ = 1008;   // clean rows staged per LDS fill: 63 KiB, so that with the static reduction words the
+                           // workgroup stays inside the 64 KiB a launch gets without an opt-in
 
 __global__ __launch_bounds__(256) void wave_pair_l1_kernel(const float* __restrict__ w, const float* __restrict__ c, int B,
                                                            int L, float scale, float* __restrict__ d_w,
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(256) void wave_pair_sorted_kernel(const float* __re
   if (tid == 0) partial[blockIdx.x] = total;
 }
 
-// Same algorithm for 256 <= NP <= 2048, with the sort in registers.  A workgroup owns RT = 8 consecutive time samples:
-// the clean values of all B clips at those samples are staged once (32-byte pieces per clip, transposed into LDS rows),
-// and every thread reads and writes its own clips' 8 waveform samples / gradients as two float4.  Per time sample the
+// Same algorithm for 256 <= NP <= 2048, with the sort in registers.  A workgroup owns RT = 4 consecutive time samples:
+// the clean values of all B clips at those samples are staged once (16-byte pieces per clip, transposed into LDS rows),
+// and every thread reads and writes its own clips' RT waveform samples / gradients as one float4.  Per time sample the
 // row is sorted with each thread holding EPT = NP/256 consecutive elements: compare-exchange partners at distance
 // j < EPT are the thread's own registers, j < 64*EPT another lane of the wave (shuffle), and only the 1-3 largest
 // distances go through LDS, so a 2048-element sort needs 6 barriers instead of 66.
@@ -466,7 +467,7 @@ NOISE_EXPORT int noise_wave_pair_l1(const float* wave, const float* clean, float
   if (B >= 64 && B <= 2048) {   // sorted algorithm: B log B instead of B^2 per time sample
     int NP = 64;
     while (NP < B) NP <<= 1;
-    if (NP >= 256) {            // register sort, 8 time samples per workgroup
+    if (NP >= 256) {            // register sort, RT time samples per workgroup
       const int pitch = B | 1;
       const size_t smem = (size_t)(B + 1) * sizeof(double) + (size_t)(NP + RT * pitch) * sizeof(float);
       const int grid = noise_cdiv(L, RT);

@@ -69,6 +69,7 @@ class DenoiserPlan:
         self.B, self.H, self.W = B, H, W
         self.device = device
         self.hp, self.wp = net.H_padding, net.W_padding
+        self.pinned = 0     # > 0 while a captured HIP graph addresses this plan's buffers
         f32 = dict(device=device, dtype=torch.float32)
         self.recs = []
         enc_blocks = net.block_plan()[0]
@@ -130,13 +131,17 @@ class DenoiserPlan:
         self.vad = torch.empty(B, **f32)
         # ---- decoder
         self.dec = []
+        self.crops = {}     # decoder block -> (cropped copy of the skip tensor, row offset, column offset)
         Hc, Wc = bott.Ho, bott.Wo
         for i, blk in enumerate(dec_blocks):
             skip = self.enc[len(self.enc) - 1 - i][-1]
+            if skip.Ho < Hc or skip.Wo < Wc:
+                raise RuntimeError(f"decoder block {i}: skip {skip.Ho}x{skip.Wo} is smaller than the decoder tensor "
+                                   f"{Hc}x{Wc} (the reference's `x + skip[..., -h:, -w:]` fails to broadcast as well)")
             if (skip.Ho, skip.Wo) != (Hc, Wc):
-                raise NotImplementedError(
-                    f"decoder block {i}: skip {skip.Ho}x{skip.Wo} vs input {Hc}x{Wc}; only padded geometries whose "
-                    "skip crops are empty are supported (pad with the searched H/W_padding)")
+                # the padding was searched for another input size: keep the last Hc rows / Wc columns of the skip tensor
+                # (train/models.py:608)
+                self.crops[i] = (torch.empty(B, Hc, Wc, skip.C, **f32), skip.Ho - Hc, skip.Wo - Wc)
             if blk["kind"] == "last":
                 m = net.decoder[i]
                 r = _Rec(name=f"decoder.{i}", kind="last", conv=m[0], bn=None, relu6=False, C=1, Cin=blk["cin"], B=B, Hi=Hc,
@@ -179,6 +184,10 @@ class DenoiserPlan:
     def ensure_backward_buffers(self):
         if self.bwd_ready:
             return
+        if self.crops:
+            # training steps run on 8000-sample segments, whose padded geometry never crops a skip tensor
+            raise NotImplementedError("backward through cropped skip connections is not scheduled: call "
+                                      "model.reset_padding() so that the padding is searched for this input size")
         f32 = dict(device=self.device, dtype=torch.float32)
         for r in self.recs:
             if r.kind != "first":
@@ -219,6 +228,8 @@ class DenoiserPlan:
         """logmag (B,H,W) raw log-magnitudes, absmax (B,) -> enhanced log-magnitudes (B,H,W), vad (B,)."""
         net = self.net
         self.logmag, self.absmax = logmag, absmax
+        if not training:
+            keep = None     # eval / validation forwards never drop attention weights
         self.keep, self.seed = keep, int(seed)
         self.p_drop = ATTN_DROPOUT if training else 0.0
         r0 = self.enc[0][0]
@@ -252,6 +263,10 @@ class DenoiserPlan:
         cur = (self.x3, None, False)
         for i, layers in enumerate(self.dec):
             skip = self.enc[len(self.enc) - 1 - i][-1].lazy()
+            if i in self.crops:
+                win, oy, ox = self.crops[i]
+                ops.crop_nhwc(skip[0], win, oy, ox)
+                skip = (win, skip[1], skip[2])
             first = True
             for r in layers:
                 if r.kind == "last":

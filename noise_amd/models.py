@@ -215,6 +215,9 @@ class VADMobileNetV2(_LightningModule):
 
     def reset_padding(self):
         """Forget the searched padding (the reference keeps the first one for the model's lifetime)."""
+        if any(q.pinned for q in self._plans.values()):
+            raise RuntimeError("reset_padding: a HIP graph captured with the current padding is still alive "
+                               "(drop the function returned by graphed_forward first)")
         self.H_padding = self.W_padding = 0
         self.searching = self.found = False
         self._plans.clear()
@@ -225,8 +228,11 @@ class VADMobileNetV2(_LightningModule):
         key = (B, H, W, self.H_padding, self.W_padding, str(device))
         p = self._plans.get(key)
         if p is None:
-            if len(self._plans) >= 4:   # plans hold activations: keep only a few geometries alive
-                self._plans.pop(next(iter(self._plans)))
+            # plans hold activations: keep only a few geometries alive.  A plan captured in a HIP graph is pinned and
+            # never evicted (the graph has its buffer addresses baked in).
+            loose = [k for k, q in self._plans.items() if not q.pinned]
+            if len(loose) >= 4:
+                self._plans.pop(loose[0])
             p = DenoiserPlan(self, B, H, W, device)
             self._plans[key] = p
         return p
@@ -257,6 +263,9 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, model, noisy, clean, keep, *params):
         losses = model._native_step(noisy, clean, keep, want_grad=True)
         ctx.model = model
+        # the native backward has already run into the shared work buffer: keep this step's gradients with this
+        # step's graph node, so a later training_step cannot replace them before .backward() is called (305 KB)
+        ctx.flat_grads = model._work_grads.clone()
         all4 = losses.clone()
         ctx.mark_non_differentiable(all4)
         return losses[0].clone(), all4
@@ -264,7 +273,7 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_all):
         model = ctx.model
-        flat = model._work_grads * g_loss
+        flat = ctx.flat_grads * g_loss
         return (None, None, None, None) + tuple(flat[o:o + n].view(s) for (o, n, s) in model._param_slices)
 
 
@@ -380,16 +389,41 @@ class VADSpectralV2(_LightningModule):
             for _ in range(2):       # padding search, plan allocation, code-object loads happen here
                 self.forward(static_in)
         cur.wait_stream(side)
+        # The graph bakes in raw device addresses: the plan's activation buffers, the flat parameter buffer and the
+        # kernel-side layouts of the STFT bases.  The closure owns references to all of them (so the caching allocator
+        # cannot hand their memory to anyone else while `run` is alive), the plan is pinned against eviction, and `run`
+        # refuses to replay once the model has moved its parameters or bases elsewhere (`.to()`, a new basis).
+        B, _, _, L = static_in.shape
+        plan = self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device)
+        plan.pinned += 1
+        flat, derived = self._flat_params, self.stft._derived
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             static_out = self.forward(static_in)
+        if self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device) is not plan or \
+                self._flat_params is not flat or self.stft._derived is not derived:
+            plan.pinned -= 1
+            raise RuntimeError("graphed_forward: buffers moved during capture")
+        model = self
 
-        def run(waveforms):
-            static_in.copy_(waveforms)
-            graph.replay()
-            return static_out
+        class _Replay:
+            """Callable owner of the captured graph; dropping it unpins the plan."""
 
-        return run
+            def __call__(self, waveforms):
+                if model._flat_params is not flat or model.stft._derived is not derived or \
+                        flat.data_ptr() != model._trainable()[0].data_ptr():
+                    raise RuntimeError("graphed_forward: the model's parameters or STFT bases were reallocated after "
+                                       "the capture (.to(), load into new storage): capture again")
+                static_in.copy_(waveforms)
+                graph.replay()
+                return static_out
+
+            def __del__(self):
+                plan.pinned -= 1
+
+            keep_alive = (plan, flat, derived, static_in)
+
+        return _Replay()
 
     # ------------------------------------------------------------------ training
     def _next_seed(self):
@@ -402,6 +436,11 @@ class VADSpectralV2(_LightningModule):
         `_work_grads` (autograd mode) or `_flat_grads` (fused mode, see `train_step_fused`)."""
         _lib.require_cuda(noisy, clean)
         self._ensure_flat()
+        if want_grad and not self.training:
+            # the backward kernels implement train-mode BatchNorm (batch statistics); gradients of an eval-mode
+            # forward (running statistics) would be silently wrong
+            raise RuntimeError("gradients are only available in train mode: call .train() (frozen-BatchNorm "
+                               "fine-tuning is not scheduled)")
         seg = self.SEGMENT
         noisy = noisy.reshape(-1, seg).contiguous().float()
         clean = clean.reshape(-1, seg).contiguous().float()
@@ -415,6 +454,12 @@ class VADSpectralV2(_LightningModule):
         lm_c, _ = stft.forward(clean.view(B, 1, 1, seg), want_phase=False)
         _, _, H, W = lm_n.shape
         training = self.training
+        if keep is not None:
+            n_tok = self.model.plan(B, H, W, dev).n_tok
+            want = (B, self.model.n_head, n_tok, n_tok)
+            if tuple(keep.shape) != want or keep.dtype != torch.uint8 or keep.device != dev or not keep.is_contiguous():
+                raise ValueError(f"attn_keep_mask must be a contiguous uint8 tensor of shape {want} on {dev}, got "
+                                 f"{tuple(keep.shape)} {keep.dtype} on {keep.device}")
         plan, enh, vad = self._spectral(lm_n, absmax, training, keep, self._next_seed())
         wave = stft._inverse_raw(enh.view(B, 1, H, W), ph, None)
         Lw = wave.shape[-1]
@@ -447,11 +492,21 @@ class VADSpectralV2(_LightningModule):
             plan.backward(bufs["d_enh"], bufs["d_vad"], self._grad_views(self._grad_target))
         return bufs["out4"]
 
+    def _take_keep_mask(self):
+        """The explicit dropout mask, if one was set, serves exactly one TRAINING step; eval / validation steps run
+        without dropout and leave it in place."""
+        if not self.training:
+            return None
+        keep, self.attn_keep_mask = self.attn_keep_mask, None
+        return keep
+
     def _shared_step(self, batch, batch_idx, stage):
         noisy, clean, _ = batch
         params = self._ensure_flat()
-        keep = self.attn_keep_mask
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        keep = self._take_keep_mask()
+        # eval-mode steps (validation outside no_grad, frozen statistics) are evaluated without a graph: the native
+        # backward implements train-mode BatchNorm only
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in params):
             self._grad_target = self._work_grads
             loss, all4 = _StepFn.apply(self, noisy, clean, keep, *params)
         else:
@@ -473,7 +528,7 @@ class VADSpectralV2(_LightningModule):
         tensor [loss, vad_loss, waveform_loss, spectral_loss] of this rank's batch (no host sync)."""
         self._ensure_flat()
         self._grad_target = self._flat_grads
-        out4 = self._native_step(noisy, clean, self.attn_keep_mask, want_grad=True)
+        out4 = self._native_step(noisy, clean, self._take_keep_mask(), want_grad=True)
         scale = 1.0
         if all_reduce is not None:
             scale = all_reduce(self._flat_grads)

@@ -30,6 +30,7 @@ _lib.register({
     "noise_pw_wgrad": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_pw_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_bn_bwd_finalize": [_P, _I, _I, _P, _P, _P, _P, _P, _L, _I, _P],
+    "noise_crop_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 })
 _lib.lib.noise_conv_max_blocks.restype = ctypes.c_int
 _lib.lib.noise_pw_wgrad_max_blocks.restype = ctypes.c_int
@@ -62,6 +63,14 @@ def _nsrc(b):
 
 def conv_out(n, s, transposed):
     return (n - 1) * s + 1 if transposed else (n - 1) // s + 1
+
+
+def crop_nhwc(src, dst, oy, ox):
+    """dst (B,Hd,Wd,C) = src (B,Hs,Ws,C)[:, oy:oy+Hd, ox:ox+Wd]."""
+    B, Hs, Ws, C = src.shape
+    _, Hd, Wd, _ = dst.shape
+    _lib.call("noise_crop_nhwc", ptr(src), ptr(dst), B, Hs, Ws, C, oy, ox, Hd, Wd, _lib.stream(),
+              nbytes=8 * dst.numel())
 
 
 def dw3x3_fwd(a, b, w, out, slab, transposed, B, Hi, Wi, C, stride):

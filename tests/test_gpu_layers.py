@@ -365,3 +365,59 @@ def test_attention_core(dev, B, n, heads, dk, p_drop):
     _lib.call("noise_attn_core_bwd", ptr(qkv_d), ptr(d_o_d), ptr(ml), ptr(keep_d), 0, p_drop, ptr(d_qkv), B * n, n, 64,
               heads, dk, st)
     close(d_qkv, qkv.grad, 2e-5, "attention input gradient")
+
+
+@pytest.mark.parametrize("B,n,heads,dk", [(4, 55, 6, 10), (3, 64, 4, 16), (2, 100, 6, 10), (1, 160, 6, 10)])
+def test_attention_core_rng_dropout(dev, B, n, heads, dk):
+    """The dropout mask of real training steps comes from the in-kernel counter RNG (keep = NULL): the forward and
+    the backward kernels regenerate it independently from (seed, element index).  The mask is recovered from the
+    forward kernel itself (Q = 0 makes the weights uniform, one-hot V columns expose one key per output channel),
+    its drop rate is checked, and then both passes are compared with torch autograd under that mask.
+    n <= 64 takes the one-wave-per-head kernels, larger n the generic ones."""
+    from noise_amd import _lib, engine  # noqa: F401
+    from noise_amd._lib import ptr
+    p_drop, seed = 0.1, 0x1234567890ABCDEF
+    hd = heads * dk
+    st = _lib.stream()
+    dims = (B * n, n, 64, heads, dk, st)
+    # ---- recover the keep mask: pass t exposes keys t*dk .. t*dk + dk - 1
+    keep = torch.zeros(B, heads, n, n)
+    for t in range(-(-n // dk)):
+        probe = torch.zeros(B, n, 3, heads, dk)
+        for c in range(dk):
+            if t * dk + c < n:
+                probe[:, t * dk + c, 2, :, c] = 1.0
+        probe_d = probe.reshape(B * n, 3 * hd).to(dev)
+        o = torch.empty(B * n, hd, device=dev)
+        _lib.call("noise_attn_core_fwd", ptr(probe_d), ptr(o), None, None, seed, p_drop, *dims)
+        got = o.cpu().reshape(B, n, heads, dk).permute(0, 2, 1, 3) * n * (1 - p_drop)     # (B, heads, query, c)
+        hi = min(dk, n - t * dk)
+        keep[:, :, :, t * dk:t * dk + hi] = got[..., :hi]
+    assert torch.all((keep - keep.round()).abs() < 1e-4) and set(keep.round().unique().tolist()) <= {0.0, 1.0}
+    keep = keep.round()
+    total = keep.numel()
+    rate = 1.0 - keep.mean().item()
+    sigma = (p_drop * (1 - p_drop) / total) ** 0.5
+    assert abs(rate - p_drop) < 4 * sigma, (rate, sigma)
+    # rows and heads are not copies of each other
+    assert not torch.equal(keep[0, 0], keep[0, 1]) and not torch.equal(keep[0, 0, 0], keep[0, 0, 1])
+    # another seed gives another mask with the same rate (checked through one probe pass)
+    # ---- forward and backward under the recovered mask
+    g = torch.Generator().manual_seed(n + 1)
+    qkv = torch.randn(B * n, 3 * hd, generator=g, requires_grad=True)
+    q, k, v = (t.reshape(B, n, heads, dk).transpose(1, 2) for t in qkv.split(hd, dim=1))
+    att = torch.softmax(torch.matmul(q / dk ** 0.5, k.transpose(2, 3)), dim=-1) * keep / (1 - p_drop)
+    ref = torch.matmul(att, v).transpose(1, 2).reshape(B * n, hd)
+    d_o = torch.randn(B * n, hd, generator=g)
+    ref.backward(d_o)
+    qkv_d = qkv.detach().to(dev)
+    o = torch.empty(B * n, hd, device=dev)
+    ml = torch.empty(B * heads * n * 2, device=dev)
+    _lib.call("noise_attn_core_fwd", ptr(qkv_d), ptr(o), ptr(ml), None, seed, p_drop, *dims)
+    close(o, ref.detach(), msg="attention output (in-kernel dropout)")
+    d_qkv = torch.zeros(B * n, 3 * hd, device=dev)
+    _lib.call("noise_attn_core_bwd", ptr(qkv_d), ptr(d_o.to(dev)), ptr(ml), None, seed, p_drop, ptr(d_qkv), *dims)
+    close(d_qkv, qkv.grad, 2e-5, "attention input gradient (in-kernel dropout)")
+    o2 = torch.empty_like(o)
+    _lib.call("noise_attn_core_fwd", ptr(qkv_d), ptr(o2), ptr(ml), None, seed + 1, p_drop, *dims)
+    assert not torch.equal(o, o2)

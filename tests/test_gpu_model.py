@@ -55,6 +55,60 @@ def test_eval_forward_golden(dev, golden_dir, tag, n_fft, hop):
         np.testing.assert_allclose(out.cpu().numpy(), g[f"{s}_out"], atol=1e-4)
 
 
+def _oracle_forward(m, w, n_fft, hop, padding=None):
+    from oracle import spectral as osp
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    bufs = osp.stft_buffers(m.stft.max_frames, n_fft, hop)
+    lm, ph = osp.stft_forward(w, bufs[0], n_fft, hop)
+    enh, vad = osp.spectral_forward(lm, sd, padding=padding)
+    return enh, vad, osp.model_forward(w, sd, bufs, n_fft, hop, padding=padding)
+
+
+def _clip(B, L, seed):
+    gen = torch.Generator().manual_seed(seed)
+    env = 0.5 - 0.5 * torch.cos(2 * np.pi * 4.0 * torch.arange(L) / 16000.0)
+    return (0.05 * torch.randn(B, 1, 1, L, generator=gen) * env + 0.02 * torch.randn(B, 1, 1, L, generator=gen)).clamp(-1, 1)
+
+
+@pytest.mark.parametrize("tag,n_fft,hop", [("A", 320, 160), ("B", 512, 128)])
+def test_forward_full_clips_vs_oracle(dev, golden_dir, tag, n_fft, hop):
+    """The whole inference forward on 10 s clips (161x1001 -> W' 1009, 704 tokens; 257x1251 -> W' 1265, 1360
+    tokens) against the CPU oracle: 1e-4 relative on the enhanced log-magnitudes, 1e-4 absolute on the waveform."""
+    m = build(n_fft, hop, dev, golden_dir, max_frames=1300).eval()
+    w = _clip(2, 160000, 7)
+    enh_ref, vad_ref, out_ref = _oracle_forward(m, w, n_fft, hop)
+    out = m(w.to(dev))
+    lm, _ = m.stft.forward(w.to(dev))
+    enh, vad = m._forward(lm)
+    assert [m.model.H_padding, m.model.W_padding] == [0, 8 if tag == "A" else 14]
+    assert rel(enh.cpu().numpy(), enh_ref.numpy()) < 1e-4
+    np.testing.assert_allclose(vad.cpu().numpy(), vad_ref.numpy(), atol=1e-4)
+    assert out.shape == out_ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), out_ref.numpy(), atol=1e-4)
+
+
+def test_padding_is_kept_and_skips_are_cropped(dev, golden_dir):
+    """The reference searches the padding on the first call and keeps it for the model's lifetime; later inputs of
+    other lengths then crop the skip tensors from the end (train/models.py:608).  Same model, three lengths, no
+    reset in between, against the oracle run with the first call's padding."""
+    m = build(320, 160, dev, golden_dir, max_frames=1300).eval()
+    for L in (8000, 16000, 160000, 8000):
+        w = _clip(2, L, L)
+        out = m(w.to(dev))
+        assert [m.model.H_padding, m.model.W_padding] == [0, 14]
+        enh_ref, vad_ref, out_ref = _oracle_forward(m, w, 320, 160, padding=(0, 14))
+        lm, _ = m.stft.forward(w.to(dev))
+        enh, vad = m._forward(lm)
+        assert rel(enh.cpu().numpy(), enh_ref.numpy()) < 1e-4, L
+        np.testing.assert_allclose(vad.cpu().numpy(), vad_ref.numpy(), atol=1e-4)
+        np.testing.assert_allclose(out.cpu().numpy(), out_ref.numpy(), atol=1e-4)
+    # an input the kept padding cannot serve fails like the reference does (output smaller than the input)
+    m2 = build(320, 160, dev, golden_dir, max_frames=1300).eval()
+    m2(_clip(1, 160000, 1).to(dev))           # padding searched for 1001 frames: W_padding = 8
+    with pytest.raises(RuntimeError):
+        m2(_clip(1, 8000, 2).to(dev))
+
+
 def test_graphed_forward_matches_eager(dev, golden_dir):
     """A HIP-graph replay of the eval forward is bit-identical to the eager launch sequence, on new input too."""
     g = np.load(os.path.join(golden_dir, "g2_eval_forward_A.npz"))
@@ -68,6 +122,35 @@ def test_graphed_forward_matches_eager(dev, golden_dir):
     np.testing.assert_allclose(run(w).cpu().numpy(), g["seg_out"], atol=1e-4)
     with pytest.raises(RuntimeError):
         m.train().graphed_forward(w)
+
+
+def test_graphed_forward_survives_other_geometries(dev, golden_dir):
+    """The captured graph addresses the plan's buffers directly: running more geometries than the plan cache holds,
+    eagerly, must neither evict that plan nor let its memory be reused."""
+    g = np.load(os.path.join(golden_dir, "g2_eval_forward_A.npz"))
+    m = build(320, 160, dev, golden_dir).eval()
+    w = torch.from_numpy(g["seg_wave"]).to(dev)
+    run = m.graphed_forward(w)
+    want = m(w).clone()
+    for B in (1, 3, 4, 5, 6, 7):               # six other plans: more than the cache keeps
+        m(torch.randn(B, 1, 1, 8000, device=dev).clamp(-1, 1) * 0.1)
+        junk = torch.randn(1 << 22, device=dev)   # would land in any freed activation buffer
+        del junk
+    assert torch.equal(run(w), want)
+    with pytest.raises(RuntimeError, match="graph"):
+        m.model.reset_padding()
+    del run
+    m.model.reset_padding()                     # allowed again once the graph's owner is gone
+    # the explicit dropout mask is validated and serves exactly one training step
+    m.train()
+    m.attn_keep_mask = torch.ones(2, 6, 55, 54, dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError, match="attn_keep_mask"):
+        m.training_step((w, w, ["a", "b"]), 0)
+    assert m.attn_keep_mask is None
+    m.eval()
+    with pytest.raises(RuntimeError, match="train mode"):
+        m._grad_target = m._work_grads
+        m._native_step(w, w, None, want_grad=True)
 
 
 def _keep(g, which, dev):
