@@ -147,6 +147,14 @@ int noise_bn_coef_eval(int C, const float* gamma, const float* beta, const float
 int noise_bn_bwd(const float* g1, const float* g2, const float* y, const float* coef, int relu6, const float* gamma,
                  float* dz, float* dgamma, float* dbeta, float* coef3, float* scratch, long npix, int C, void* stream);
 
+/* noise_bn_bwd without a workspace argument.  It has no counterpart in the reference: it exists for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
+ * partial slab lives in a 2 MiB static device array that each GPU holds until the process ends; C <= 256 (larger C
+ * is refused).  Calls that overlap on one GPU share that array and race: issue them on one stream. */
+int noise_bn_bwd_static(const float* g1, const float* g2, const float* y, const float* coef, int relu6,
+                        const float* gamma, float* dz, float* dgamma, float* dbeta, float* coef3, long npix, int C,
+                        void* stream);
+
 /* the finalize half of noise_bn_bwd, for sums left by a consumer's backward epilogue */
 int noise_bn_bwd_finalize(const float* slab, int slab_rows, int row_stride, const float* coef, const float* gamma,
                           float* dgamma, float* dbeta, float* coef3, long npix, int C, void* stream);

@@ -11,6 +11,8 @@
 
 namespace {
 
+constexpr int BN_BWD_MAX_ROWS = 1024;   // grid cap of bn_bwd_reduce_kernel = rows of its partial slab
+
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ slab, int nrows, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -159,7 +161,7 @@ NOISE_EXPORT int noise_bn_bwd(const float* g1, const float* g2, const float* y, 
   NOISE_REQUIRE(g1 && y && coef && gamma && dgamma && dbeta && coef3 && scratch, "noise_bn_bwd: null pointer");
   NOISE_REQUIRE(C >= 4 && C % 4 == 0 && npix > 0, "noise_bn_bwd: bad shape");
   const int PPB = 256 / (C / 4);
-  const int grid = noise_grid(npix, PPB * 4, 1024);
+  const int grid = noise_grid(npix, PPB * 4, BN_BWD_MAX_ROWS);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)PPB * 2 * C * sizeof(float), st, g1, g2, y, coef,
                      relu6, C, npix, dz, scratch);
@@ -168,6 +170,37 @@ NOISE_EXPORT int noise_bn_bwd(const float* g1, const float* g2, const float* y, 
                      gamma, coef, dgamma, dbeta, coef3);
   NOISE_CHECK_LAUNCH("noise_bn_bwd/finalize");
   return 0;
+}
+
+// ---- noise_bn_bwd for callers that cannot allocate ---------------------------------------------------------------
+// Same two kernels; the per-workgroup partial slab lives in a file-scope device array instead of a caller workspace.
+// Each GPU the library runs on holds its own copy of the array (at its own address) until the process ends; the
+// address is looked up once per device.  The reduce kernel writes rows [0, grid) of the slab before the finalize
+// kernel reads exactly those rows, so nothing has to start at zero; calls that overlap on one GPU (two streams)
+// share the array and race.
+constexpr int BN_STATIC_MAX_C = 256;      // widest BatchNorm served
+static __device__ __align__(256) float scratch[BN_BWD_MAX_ROWS * 2 * BN_STATIC_MAX_C];   // 2 MiB per GPU
+
+constexpr int BN_STATIC_MAX_DEVICES = 64;
+static float* g_scratch_ptr[BN_STATIC_MAX_DEVICES];   // device address of `scratch` on each GPU (null: not looked up yet)
+
+NOISE_EXPORT int noise_bn_bwd_static(const float* g1, const float* g2, const float* y, const float* coef, int relu6,
+                                     const float* gamma, float* dz, float* dgamma, float* dbeta, float* coef3,
+                                     long npix, int C, void* stream) {
+  NOISE_REQUIRE(C <= BN_STATIC_MAX_C, "noise_bn_bwd_static: C=%d exceeds the static workspace (at most %d channels); "
+                "use noise_bn_bwd with a caller workspace", C, BN_STATIC_MAX_C);
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  NOISE_REQUIRE(e == hipSuccess && dev >= 0 && dev < BN_STATIC_MAX_DEVICES, "noise_bn_bwd_static: no current device (%s)",
+                hipGetErrorString(e));
+  float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (ws == nullptr) {
+    e = hipGetSymbolAddress((void**)&ws, HIP_SYMBOL(scratch));
+    NOISE_REQUIRE(e == hipSuccess && ws != nullptr, "noise_bn_bwd_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                  hipGetErrorString(e));
+    __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);   // concurrent first calls look up the same address
+  }
+  return noise_bn_bwd(g1, g2, y, coef, relu6, gamma, dz, dgamma, dbeta, coef3, ws, npix, C, stream);
 }
 
 // Second half of noise_bn_bwd alone, for sums that a consumer's backward epilogue already left in `slab`
