@@ -137,6 +137,18 @@ int noise_pw_bwd(const float* dz, const float* y_out, const float* coef3, const 
                  float* scratch, const float* g_other, const float* epi_coef, int epi_relu6, float* stats_slab,
                  int* slab_rows, long npix, int Cout, int Cin, void* stream);
 
+/* ---- block-fused bf16 inference (eval mode, BatchNorm folded): models.py:348-407, :299-345, :583-612 ------------ */
+/* One inverted-residual block with stride 2 per launch: expand 1x1 + ReLU6 -> depthwise 3x3 (transposed != 0:
+ * ConvTranspose2d) + ReLU6 -> project 1x1, the hidden tensor staying in LDS.  x [B][Hi][Wi][Cin] and the optional skip
+ * [B][Hs][Ws][Cin] (added to x at rows soy.., columns sox..: the crop of models.py:608) are NHWC bf16, or fp32 when
+ * in_f32; out [B][Ho][Wo][Cout] is bf16, or fp32 when out_f32 (Ho = (Hi-1)/2+1, transposed: 2*Hi-1).  Weights with
+ * the BatchNorm scale folded in, zero padded: w1 [ceil16(Hid)][ceil32(Cin)] bf16, b1 [ceil16(Hid)], wd [9][ceil8(Hid)]
+ * fp32 (tap-major), b2 [ceil8(Hid)], w3 [ceil16(Cout)][ceil32(Hid)] bf16, b3 [ceil16(Cout)].  Served channel triples:
+ * the blocks of train/configs/spectralv2.yaml:77-84; others are refused (use the per-layer fp32 entry points). */
+int noise_fused_ir_block(const void* x, const void* skip, int in_f32, int Hs, int Ws, int soy, int sox, const void* w1,
+                         const float* b1, const float* wd, const float* b2, const void* w3, const float* b3, void* out,
+                         int out_f32, int transposed, int B, int Hi, int Wi, int Cin, int Hid, int Cout, void* stream);
+
 /* ---- BatchNorm2d in train / eval mode (every norm_layer of models.py:371-397, :1151-1159) ---- */
 int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, long count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
