@@ -149,6 +149,24 @@ int noise_fused_ir_block(const void* x, const void* skip, int in_f32, int Hs, in
                          const float* b1, const float* wd, const float* b2, const void* w3, const float* b3, void* out,
                          int out_f32, int transposed, int B, int Hi, int Wi, int Cin, int Hid, int Cout, void* stream);
 
+/* Head of the fused network: normalise (models.py:614-622) + left/top pad (:589) -> first Conv2d 1->32 s2 + BN + ReLU6
+ * (:1151-1159; kept as skip tensor a0) -> depthwise 3x3 s1 + BN + ReLU6 -> 1x1 32->16 + BN (:385-396; skip tensor a1).
+ * w0 [32][32] bf16: row c = the 9 folded taps of channel c at k = 0..8 and again at k = 9..17 (the kernel multiplies the
+ * bf16-rounded input and its rounding remainder), zeros after; wd [9][32] fp32; w3 [16][32] bf16.
+ * a0 [B][H1][W1][32], a1 [B][H1][W1][16] bf16, H1 = (H + hp - 1)/2 + 1, W1 likewise. */
+int noise_fused_head(const float* logmag, const float* absmax, const void* w0, const float* b0, const float* wd,
+                     const float* b2, const void* w3, const float* b3, void* a0, void* a1, int B, int H, int W, int hp,
+                     int wp, float pad_value, void* stream);
+/* Tail of the fused network: s = d2 + a1 (skip, cropped) -> depthwise ConvTranspose2d 3x3 s1 + BN + ReLU6 -> 1x1
+ * 16->32 + BN (models.py:1193-1201) -> + a0 (skip, cropped) -> last ConvTranspose2d 32->1 s2 with bias (:1164-1171) ->
+ * crop (:610) -> enh = clamp(logmag/max + filt, -1, 1)*max (:762-763).  d2 [B][h][w][16] bf16; the skips are read at
+ * their crop offsets (oy, ox) inside their own [Hs][Ws]; wd [9][16] fp32; w3 [32][32] bf16 (columns >= 16 zero);
+ * wl [16][32] bf16 (row = tap, column = channel); enh / filt [B][H][W] fp32 (either may be NULL). */
+int noise_fused_tail(const void* d2, const void* a1, int Hs1, int Ws1, int oy1, int ox1, const void* a0, int Hs0,
+                     int Ws0, int oy0, int ox0, const float* wd, const float* b2, const void* w3, const float* b3,
+                     const void* wl, float bias, const float* logmag, const float* absmax, float* enh, float* filt,
+                     int B, int h, int w, int H, int W, void* stream);
+
 /* ---- BatchNorm2d in train / eval mode (every norm_layer of models.py:371-397, :1151-1159) ---- */
 int noise_bn_finalize_fwd(const float* slab, int slab_rows, int C, long count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,

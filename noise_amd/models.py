@@ -222,10 +222,12 @@ class VADMobileNetV2(_LightningModule):
         self.searching = self.found = False
         self._plans.clear()
 
-    def plan(self, B, H, W, device):
+    def plan(self, B, H, W, device, fused=False):
+        """Buffers + schedule for one geometry: the per-layer fp32 engine, or (fused=True) the block-fused bf16
+        inference kernels."""
         if not self.searching and not self.found:
             self._search_padding(H, W)
-        key = (B, H, W, self.H_padding, self.W_padding, str(device))
+        key = (B, H, W, self.H_padding, self.W_padding, str(device), bool(fused))
         p = self._plans.get(key)
         if p is None:
             # plans hold activations: keep only a few geometries alive.  A plan captured in a HIP graph is pinned and
@@ -233,7 +235,11 @@ class VADMobileNetV2(_LightningModule):
             loose = [k for k, q in self._plans.items() if not q.pinned]
             if len(loose) >= 4:
                 self._plans.pop(loose[0])
-            p = DenoiserPlan(self, B, H, W, device)
+            if fused:
+                from .fused import FusedDenoiser
+                p = FusedDenoiser(self, B, H, W, device)
+            else:
+                p = DenoiserPlan(self, B, H, W, device)
             self._plans[key] = p
         return p
 
@@ -295,6 +301,9 @@ class VADSpectralV2(_LightningModule):
         self._work_grads = None
         self._param_slices = []
         self._step_bufs = {}
+        # "bf16": eval-mode forwards run the block-fused kernels (bf16 storage, fp32 accumulation, BatchNorm folded);
+        # training and "fp32" run the per-layer fp32 kernels
+        self.inference_dtype = "fp32"
         self.attn_keep_mask = None     # optional explicit (B,heads,n,n) uint8 keep-mask for the next training step
         self.attn_seed = 0x5EED
 
@@ -348,9 +357,18 @@ class VADSpectralV2(_LightningModule):
     # ------------------------------------------------------------------ inference
     def _spectral(self, log_magnitudes, absmax, training, keep=None, seed=0):
         B, _, H, W = log_magnitudes.shape
+        if self._fused_eval(training):
+            plan = self.model.plan(B, H, W, log_magnitudes.device, fused=True)
+            enh, vad = plan.forward(log_magnitudes.view(B, H, W), absmax)
+            return plan, enh, vad
         plan = self.model.plan(B, H, W, log_magnitudes.device)
         enh, vad = plan.forward(log_magnitudes.view(B, H, W), absmax, training, keep, seed)
         return plan, enh, vad
+
+    def _fused_eval(self, training):
+        if self.inference_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"inference_dtype must be 'fp32' or 'bf16', got {self.inference_dtype!r}")
+        return self.inference_dtype == "bf16" and not training
 
     def _forward(self, log_magnitudes):
         """(B,1,F,T) -> enhanced log-magnitudes (B,1,F,T), vad (B,1)   (train/models.py:758-764)."""
@@ -394,13 +412,14 @@ class VADSpectralV2(_LightningModule):
         # cannot hand their memory to anyone else while `run` is alive), the plan is pinned against eviction, and `run`
         # refuses to replay once the model has moved its parameters or bases elsewhere (`.to()`, a new basis).
         B, _, _, L = static_in.shape
-        plan = self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device)
+        fused = self._fused_eval(False)
+        plan = self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device, fused=fused)
         plan.pinned += 1
         flat, derived = self._flat_params, self.stft._derived
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             static_out = self.forward(static_in)
-        if self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device) is not plan or \
+        if self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device, fused=fused) is not plan or \
                 self._flat_params is not flat or self.stft._derived is not derived:
             plan.pinned -= 1
             raise RuntimeError("graphed_forward: buffers moved during capture")

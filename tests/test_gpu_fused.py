@@ -67,3 +67,77 @@ def test_fused_ir_block(dev, cin, hid, cout, transposed, in_f32, out_f32, B, H, 
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     _check(got, ref, what=f"ir block {cin}->{hid}->{cout}")
+
+
+LAYER_CONFIG = [[1, 32, 1, [3, 3], [2, 2]], [1, 16, 1, [3, 3], [1, 1]], [3, 24, 1, [3, 3], [2, 2]],
+                [3, 32, 1, [3, 3], [2, 2]], [3, 64, 1, [3, 3], [2, 2]]]
+
+
+def _build(n_fft, hop, dev, golden_dir, tame=True):
+    import os
+    from noise_amd import VADSpectralV2
+    m = VADSpectralV2(n_fft=n_fft, hop_length=hop, win_length=n_fft, window="hann", nhead=6, num_layers=1, dropout=0.0,
+                      layer_config=[list(r) for r in LAYER_CONFIG], pad_value=-1, max_frames=1300)
+    g = np.load(os.path.join(golden_dir, "g2_state_dict.npz"))
+    m.load_state_dict({k: torch.from_numpy(g[k]) for k in g.files}, strict=False)
+    gen = torch.Generator().manual_seed(5)
+    _randomise_bn(m.model, gen)        # running statistics that differ from the freshly initialised (0, 1)
+    if tame:
+        with torch.no_grad():          # keep most of the enhanced log-magnitudes inside the [-1, 1] clamp
+            m.model.decoder[-1][0].weight.mul_(0.05)
+            m.model.decoder[-1][0].bias.zero_()
+    return m.to(dev).eval()
+
+
+def _clip(B, L, seed):
+    gen = torch.Generator().manual_seed(seed)
+    env = 0.5 - 0.5 * torch.cos(2 * np.pi * 4.0 * torch.arange(L) / 16000.0)
+    return (0.05 * torch.randn(B, 1, 1, L, generator=gen) * env + 0.02 * torch.randn(B, 1, 1, L, generator=gen)).clamp(-1, 1)
+
+
+def _snr_db(got, ref):
+    got, ref = got.double(), ref.double()
+    return float(10 * torch.log10(ref.pow(2).sum() / (got - ref).pow(2).sum().clamp_min(1e-30)))
+
+
+@pytest.mark.parametrize("tag,n_fft,hop", [("A", 320, 160), ("B", 512, 128)])
+@pytest.mark.parametrize("L,B,first_L,tame", [(8000, 3, None, True), (16000, 2, None, True), (160000, 2, None, True),
+                                              (160000, 1, 8000, True), (160000, 2, None, False)])
+def test_fused_forward_vs_oracle(dev, golden_dir, tag, n_fft, hop, L, B, first_L, tame):
+    """Whole bf16 inference forward (STFT fp32 -> fused network -> iSTFT fp32) against the fp32 CPU oracle.
+    Stated bf16 tolerance: network output (the additive mask in normalised log-magnitude) within 1 % rms / 4 % max
+    of its largest value (measured: 0.7 % rms, about 25 roundings to 8 significant bits along the path); VAD logit
+    within 0.03.  What that means for the waveform depends on the size of the mask, which is multiplied by
+    max|log-magnitude| (about 6.9) and exponentiated: with the fixture's untrained weights as they are (|mask| up to
+    ~1) the enhanced waveform keeps an SNR >= 33 dB against the fp32 oracle (measured 36 dB); with the last layer
+    scaled to 5 % (`tame`, masks of the size of a small correction) >= 55 dB (measured 64-67 dB).
+    `first_L`: the padding is searched on a first call of another length, so the skips are cropped (models.py:608)."""
+    from oracle import spectral as osp
+    m = _build(n_fft, hop, dev, golden_dir, tame)
+    m.inference_dtype = "bf16"
+    if first_L is not None:
+        m(_clip(1, first_L, 1).to(dev))
+        if tag == "B":      # 63 frames -> W_padding 2; 1009 + 2 = 1011 columns -> 506 at half resolution, 505 coming back
+            L = 128 * 1008  # up: the two full-resolution skips are cropped by one column
+    padding = (m.model.H_padding, m.model.W_padding) if first_L is not None else None
+    w = _clip(B, L, L + B)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    bufs = osp.stft_buffers(1300, n_fft, hop)
+    lm, ph = osp.stft_forward(w, bufs[0], n_fft, hop)
+    mx = lm.abs().reshape(B, 1, -1).max(dim=-1, keepdim=True)[0].unsqueeze(2) + 1e-6
+    filt_ref, vad_ref = osp.denoiser(lm / mx, sd, padding=padding)
+    out_ref = osp.model_forward(w, sd, bufs, n_fft, hop, padding=padding)
+    wd = w.to(dev)
+    out = m(wd)
+    lm_d, _, amax = m.stft.forward(wd, return_absmax=True)
+    H, W = lm_d.shape[2:]
+    plan = m.model.plan(B, H, W, dev, fused=True)
+    enh, vad, filt = plan.forward(lm_d.view(B, H, W), amax, want_filt=True)
+    rms, worst = _check(filt.cpu().view(B, 1, H, W), filt_ref, what=f"mask {tag} L={L}")
+    assert (vad.cpu().view(-1) - vad_ref.view(-1)).abs().max() < 0.03
+    snr = _snr_db(out.cpu(), out_ref)
+    print(f"{tag} L={L} B={B} crop={first_L} tame={tame}: mask rms {rms:.2e} max {worst:.2e}  wave SNR {snr:.1f} dB")
+    assert snr >= (55.0 if tame else 33.0)
+    # fp32 mode of the same model stays on the per-layer kernels and the tight tolerance
+    m.inference_dtype = "fp32"
+    np.testing.assert_allclose(m(wd).cpu().numpy(), out_ref.numpy(), atol=1e-4)
