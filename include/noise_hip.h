@@ -142,28 +142,31 @@ int noise_pw_bwd(const float* dz, const float* y_out, const float* coef3, const 
  * ConvTranspose2d) + ReLU6 -> project 1x1, the hidden tensor staying in LDS.  x [B][Hi][Wi][Cin] and the optional skip
  * [B][Hs][Ws][Cin] (added to x at rows soy.., columns sox..: the crop of models.py:608) are NHWC bf16, or fp32 when
  * in_f32; out [B][Ho][Wo][Cout] is bf16, or fp32 when out_f32 (Ho = (Hi-1)/2+1, transposed: 2*Hi-1).  Weights with
- * the BatchNorm scale folded in, zero padded: w1 [ceil16(Hid)][ceil32(Cin)] bf16, b1 [ceil16(Hid)], wd [9][ceil8(Hid)]
- * fp32 (tap-major), b2 [ceil8(Hid)], w3 [ceil16(Cout)][ceil32(Hid)] bf16, b3 [ceil16(Cout)].  Served channel triples:
- * the blocks of train/configs/spectralv2.yaml:77-84; others are refused (use the per-layer fp32 entry points). */
+ * the BatchNorm scale folded in, zero padded, "half" = IEEE binary16 (inside a kernel every tile is a block input or
+ * sits behind a ReLU6, so half loses no range and keeps 11 bits; only what leaves a kernel is rounded to bf16):
+ * w1 [ceil16(Hid)][ceil32(Cin)] half, b1 [ceil16(Hid)] fp32, wd [9][ceil8(Hid)] half (tap-major), b2 [ceil8(Hid)] half,
+ * w3 [ceil16(Cout)][ceil32(Hid)] half, b3 [ceil16(Cout)] fp32.  Served: the blocks of train/configs/spectralv2.yaml:77-84
+ * (32->96->64 writes fp32 for the attention kernels, 64->192->32 reads fp32 from them); others are refused (use the
+ * per-layer fp32 entry points). */
 int noise_fused_ir_block(const void* x, const void* skip, int in_f32, int Hs, int Ws, int soy, int sox, const void* w1,
-                         const float* b1, const float* wd, const float* b2, const void* w3, const float* b3, void* out,
+                         const float* b1, const void* wd, const void* b2, const void* w3, const float* b3, void* out,
                          int out_f32, int transposed, int B, int Hi, int Wi, int Cin, int Hid, int Cout, void* stream);
 
 /* Head of the fused network: normalise (models.py:614-622) + left/top pad (:589) -> first Conv2d 1->32 s2 + BN + ReLU6
  * (:1151-1159; kept as skip tensor a0) -> depthwise 3x3 s1 + BN + ReLU6 -> 1x1 32->16 + BN (:385-396; skip tensor a1).
- * w0 [32][32] bf16: row c = the 9 folded taps of channel c at k = 0..8 and again at k = 9..17 (the kernel multiplies the
- * bf16-rounded input and its rounding remainder), zeros after; wd [9][32] fp32; w3 [16][32] bf16.
- * a0 [B][H1][W1][32], a1 [B][H1][W1][16] bf16, H1 = (H + hp - 1)/2 + 1, W1 likewise. */
-int noise_fused_head(const float* logmag, const float* absmax, const void* w0, const float* b0, const float* wd,
-                     const float* b2, const void* w3, const float* b3, void* a0, void* a1, int B, int H, int W, int hp,
+ * w0 [32][32] half: row c = folded taps 0..7 of channel c at k = 0..7 and again at k = 8..15, tap 8 at k = 16 and 17
+ * (the kernel multiplies the half-rounded input and its rounding remainder), zeros after; wd [9][32], b2 [32] half;
+ * w3 [16][32] half.  a0 [B][H1][W1][32], a1 [B][H1][W1][16] bf16, H1 = (H + hp - 1)/2 + 1, W1 likewise. */
+int noise_fused_head(const float* logmag, const float* absmax, const void* w0, const float* b0, const void* wd,
+                     const void* b2, const void* w3, const float* b3, void* a0, void* a1, int B, int H, int W, int hp,
                      int wp, float pad_value, void* stream);
 /* Tail of the fused network: s = d2 + a1 (skip, cropped) -> depthwise ConvTranspose2d 3x3 s1 + BN + ReLU6 -> 1x1
  * 16->32 + BN (models.py:1193-1201) -> + a0 (skip, cropped) -> last ConvTranspose2d 32->1 s2 with bias (:1164-1171) ->
  * crop (:610) -> enh = clamp(logmag/max + filt, -1, 1)*max (:762-763).  d2 [B][h][w][16] bf16; the skips are read at
- * their crop offsets (oy, ox) inside their own [Hs][Ws]; wd [9][16] fp32; w3 [32][32] bf16 (columns >= 16 zero);
- * wl [16][32] bf16 (row = tap, column = channel); enh / filt [B][H][W] fp32 (either may be NULL). */
+ * their crop offsets (oy, ox) inside their own [Hs][Ws]; wd [9][16], b2 [16] half; w3 [32][32] half (columns >= 16
+ * zero); wl [16][32] half (row = tap, column = channel); enh / filt [B][H][W] fp32 (either may be NULL). */
 int noise_fused_tail(const void* d2, const void* a1, int Hs1, int Ws1, int oy1, int ox1, const void* a0, int Hs0,
-                     int Ws0, int oy0, int ox0, const float* wd, const float* b2, const void* w3, const float* b3,
+                     int Ws0, int oy0, int ox0, const void* wd, const void* b2, const void* w3, const float* b3,
                      const void* wl, float bias, const float* logmag, const float* absmax, float* enh, float* filt,
                      int B, int h, int w, int H, int W, void* stream);
 

@@ -1,7 +1,7 @@
 """Block-fused bf16 inference of the denoiser U-Net (eval mode, BatchNorm folded into the weights).
 
 Host side of `csrc/fused.hip`: folds the BatchNorm of every conv of train/models.py:348-407 / :299-345 /
-:1151-1173 into bf16 weights + fp32 biases in the padded layouts the kernels read, and schedules
+:1151-1173 into half-precision weights + biases in the padded layouts the kernels read, and schedules
 `Base._forward` / `BaseSpectral._forward` (train/models.py:583-612, :758-764) as
 
     head (first conv + block 1)  ->  3 strided blocks  ->  attention (fp32 kernels)  ->  3 transposed blocks
@@ -54,16 +54,19 @@ class IrBlockWeights:
         s1, sh1 = bn_fold(seq[0][1])
         s2, sh2 = bn_fold(seq[1][1])
         s3, sh3 = bn_fold(seq[3])
-        w1 = seq[0][0].weight.detach().float().view(hid, cin) * s1[:, None]
+        # the kernels keep hidden activations divided by 6 (ReLU6 = clamp to [0, 1]): 1/6 goes into what produces them
+        # (w1, b1, b2; the depthwise weights map h/6 to h/6 unchanged), 6 into what consumes them (w3)
+        w1 = seq[0][0].weight.detach().float().view(hid, cin) * s1[:, None] / 6.0
+        sh1, sh2 = sh1 / 6.0, sh2 / 6.0
         wd = seq[1][0].weight.detach().float().view(hid, 9) * s2[:, None]
-        w3 = seq[2].weight.detach().float().view(cout, hid) * s3[:, None]
+        w3 = seq[2].weight.detach().float().view(cout, hid) * s3[:, None] * 6.0
         ht, g, ct = _rup(hid, 16), _rup(hid, 8), _rup(cout, 16)
         self.cin, self.hid, self.cout = cin, hid, cout
-        self.w1 = pad_matrix(w1, ht, _rup(cin, 32), torch.bfloat16)
+        self.w1 = pad_matrix(w1, ht, _rup(cin, 32), torch.float16)
         self.b1 = pad_vector(sh1, ht)
-        self.wd = pad_matrix(wd.t(), 9, g, torch.float32)          # tap-major
-        self.b2 = pad_vector(sh2, g)
-        self.w3 = pad_matrix(w3, ct, _rup(hid, 32), torch.bfloat16)
+        self.wd = pad_matrix(wd.t(), 9, g, torch.float16)          # tap-major
+        self.b2 = pad_vector(sh2, g).half()
+        self.w3 = pad_matrix(w3, ct, _rup(hid, 32), torch.float16)
         self.b3 = pad_vector(sh3, ct)
 
 
@@ -94,14 +97,16 @@ class HeadWeights:
 
     def __init__(self, first, seq):
         s0, sh0 = bn_fold(first[1])
-        w0 = first[0].weight.detach().float().view(32, 9) * s0[:, None]
-        self.w0 = pad_matrix(torch.cat([w0, w0], dim=1), 32, 32, torch.bfloat16)    # taps at k = 0..8 and 9..17
+        w0 = first[0].weight.detach().float().view(32, 9) * s0[:, None] / 6.0     # hidden activations are kept / 6
+        sh0 = sh0 / 6.0
+        # k = 0..7: taps 0..7 (for the rounded input), k = 8..15: taps 0..7 again (for its remainder), k = 16, 17: tap 8
+        self.w0 = pad_matrix(torch.cat([w0[:, :8], w0[:, :8], w0[:, 8:], w0[:, 8:]], dim=1), 32, 32, torch.float16)
         self.b0 = sh0.contiguous()
         s2, sh2 = bn_fold(seq[0][1])
         s3, sh3 = bn_fold(seq[2])
-        self.wd = (seq[0][0].weight.detach().float().view(32, 9) * s2[:, None]).t().contiguous()
-        self.b2 = sh2.contiguous()
-        self.w3 = pad_matrix(seq[1].weight.detach().float().view(16, 32) * s3[:, None], 16, 32, torch.bfloat16)
+        self.wd = (seq[0][0].weight.detach().float().view(32, 9) * s2[:, None]).t().contiguous().half()
+        self.b2 = (sh2 / 6.0).contiguous().half()
+        self.w3 = pad_matrix(seq[1].weight.detach().float().view(16, 32) * s3[:, None] * 6.0, 16, 32, torch.float16)
         self.b3 = sh3.contiguous()
 
 
@@ -111,11 +116,12 @@ class TailWeights:
     def __init__(self, seq, last):
         s2, sh2 = bn_fold(seq[0][1])
         s3, sh3 = bn_fold(seq[2])
-        self.wd = (seq[0][0].weight.detach().float().view(16, 9) * s2[:, None]).t().contiguous()
-        self.b2 = sh2.contiguous()
-        self.w3 = pad_matrix(seq[1].weight.detach().float().view(32, 16) * s3[:, None], 32, 32, torch.bfloat16)
+        # the depthwise input (a sum of two block outputs) is not scaled, its output is kept / 6
+        self.wd = (seq[0][0].weight.detach().float().view(16, 9) * s2[:, None] / 6.0).t().contiguous().half()
+        self.b2 = (sh2 / 6.0).contiguous().half()
+        self.w3 = pad_matrix(seq[1].weight.detach().float().view(32, 16) * s3[:, None] * 6.0, 32, 32, torch.float16)
         self.b3 = sh3.contiguous()
-        self.wl = pad_matrix(last.weight.detach().float().view(32, 9).t(), 16, 32, torch.bfloat16)   # [tap][channel]
+        self.wl = pad_matrix(last.weight.detach().float().view(32, 9).t(), 16, 32, torch.float16)   # [tap][channel]
         self.bias = float(last.bias.detach().float().item())
 
 
