@@ -56,6 +56,24 @@ int noise_istft_bwd_sym(const float* d_wave, const float* wave_out, const float*
                         const float* inv_basisF, const float* window_sum, float* d_logmag, int accumulate,
                         int B, int T, int n_fft, int hop, void* stream);
 
+/* FFT variants of the same three operations (same reference lines), for bases that are a window times the real DFT, as
+ * the reference registers them (models.py:413-458): forward_basis[f][n] = w[n] (cos, -sin)(2 pi f n / N),
+ * inverse_basis[f][n] = c_f ws[n] (cos, -sin)(2 pi f n / N) / N, c = 1 for the DC / Nyquist rows and 2 otherwise.  The
+ * caller checks that structure and passes window = w (forward) or syn_window = ws (inverse and adjoint), each [n_fft],
+ * plus the twiddle tables tw1 [n_fft/2][2] = e^{-2 pi i j / (n_fft/2)} and tw2 [n_fft/2 + 1][2] = e^{-2 pi i k / n_fft}
+ * as (re, im) pairs.  A frame is one complex FFT of n_fft/2 points done in two register passes through LDS plus a split
+ * step; about 1/15 of the arithmetic of the dense products.  noise_fft_supported(n_fft) != 0 for the sizes served
+ * (320 = 2*16*10 and 512 = 2*16*16); results agree with the dense entry points to fp32 rounding. */
+int noise_fft_supported(int n_fft);
+int noise_stft_fwd_fft(const float* wave, const float* window, const float* tw1, const float* tw2, float* logmag,
+                       float* phase, float* absmax, int B, int L, int n_fft, int hop, void* stream);
+int noise_istft_fwd_fft(const float* logmag, const float* phase, const float* syn_window, const float* tw1, const float* tw2,
+                        const float* window_sum, const float* vad_logit, float* wave_out, int B, int T, int n_fft, int hop,
+                        void* stream);
+int noise_istft_bwd_fft(const float* d_wave, const float* wave_out, const float* logmag, const float* phase,
+                        const float* syn_window, const float* tw1, const float* tw2, const float* window_sum,
+                        float* d_logmag, int accumulate, int B, int T, int n_fft, int hop, void* stream);
+
 /* ---- deferred folds of per-workgroup slabs (no counterpart in the reference: ATen reduces inside each op) ------ */
 /* out[j] = sum over rows of slab[row*row_stride + j], j < ncols; with tr_k > 0 column j = k*tr_C + c goes to
  * out[c*tr_k + k] (the (C, k) layout of a depthwise weight).  noise_pw_bwd and noise_dw3x3_bwd called with dw = NULL

@@ -59,6 +59,32 @@ def folded(basis, n_fft):
     return out.contiguous()
 
 
+def fft_tables(forward_basis, inverse_basis, n_fft, tol=2e-6):
+    """Windows and twiddle tables for the FFT kernels, or None when the registered bases are not `window x real DFT`
+    (a checkpoint with edited bases): forward_basis[f][n] = w[n] (cos, -sin)(2 pi f n / N), inverse_basis[f][n] =
+    c_f ws[n] (cos, -sin)(2 pi f n / N) / N with c = 1 for the DC / Nyquist rows and 2 otherwise
+    (train/models.py:413-458).  Returns (w, ws, tw1, tw2): tw1[j] = e^{-2 pi i j / (N/2)}, tw2[k] = e^{-2 pi i k / N}."""
+    N, F = n_fft, n_fft // 2 + 1
+    fb, ib = forward_basis.double().cpu(), inverse_basis.double().cpu()
+    n = torch.arange(N, dtype=torch.float64)
+    ang = 2 * np.pi * torch.arange(F, dtype=torch.float64)[:, None] * n / N
+    w, ws = fb[0], ib[0] * N
+    c = torch.full((F, 1), 2.0, dtype=torch.float64)
+    c[0] = c[-1] = 1.0
+    ok = ((fb[:F] - torch.cos(ang) * w).abs().max() <= tol * fb.abs().max() and
+          (fb[F:] + torch.sin(ang) * w).abs().max() <= tol * fb.abs().max() and
+          (ib[:F] - c * ws * torch.cos(ang) / N).abs().max() <= tol * ib.abs().max() and
+          (ib[F:] + c * ws * torch.sin(ang) / N).abs().max() <= tol * ib.abs().max())
+    if not ok:
+        return None
+    j = torch.arange(N // 2, dtype=torch.float64)
+    k = torch.arange(N // 2 + 1, dtype=torch.float64)
+    tw1 = torch.stack([torch.cos(2 * np.pi * j / (N // 2)), -torch.sin(2 * np.pi * j / (N // 2))], dim=1)
+    tw2 = torch.stack([torch.cos(2 * np.pi * k / N), -torch.sin(2 * np.pi * k / N)], dim=1)
+    dev = forward_basis.device
+    return tuple(t.float().contiguous().to(dev) for t in (w, ws, tw1, tw2))
+
+
 def is_symmetric(basis, n_fft, tol=1e-6):
     """Re rows even, Im rows odd about n_fft/2 (to `tol` of the largest entry): true whenever the window obeys
     w[n] = w[n_fft - n], as every periodic window of scipy.signal.get_window does."""
@@ -117,19 +143,28 @@ class STFT(torch.nn.Module):
         self.register_buffer("window_sum", window_sum)
         self._derived = None  # (key, symmetric, forward layout, inverse layout) rebuilt when buffers move/change
         self.use_symmetry = True  # False forces the general kernels (any basis)
+        self.use_fft = True       # False forces the dense-basis kernels
 
     # -- kernel-side layouts of the two bases, derived lazily from the registered buffers
     def _bases(self):
         """(symmetric, forward general, inverse general, forward folded, inverse folded); the folded layouts are
         None when either basis lacks the mirror symmetry (or `use_symmetry` is off)."""
         fb, ib = self.forward_basis, self.inverse_basis
-        key = (fb.data_ptr(), fb._version, ib.data_ptr(), ib._version, self.use_symmetry)
+        key = (fb.data_ptr(), fb._version, ib.data_ptr(), ib._version, self.use_symmetry, self.use_fft)
         if self._derived is None or self._derived[0] != key:
             f2, i2 = fb[:, 0, :], ib[:, 0, :]
             sym = self.use_symmetry and is_symmetric(f2, self.n_fft) and is_symmetric(i2, self.n_fft)
+            fft = None
+            if self.use_fft and fb.is_cuda and _lib.lib.noise_fft_supported(self.n_fft) and self.n_fft % self.hop_length == 0:
+                fft = fft_tables(f2, i2, self.n_fft)
             self._derived = (key, sym, interleaved_transposed(f2, self.n_fft), interleaved_transposed(i2, self.n_fft),
-                             folded(f2, self.n_fft) if sym else None, folded(i2, self.n_fft) if sym else None)
-        return self._derived[1:]
+                             folded(f2, self.n_fft) if sym else None, folded(i2, self.n_fft) if sym else None, fft)
+        return self._derived[1:6]
+
+    def _fft(self):
+        """(analysis window, synthesis window, tw1, tw2) when the FFT kernels can serve the registered bases."""
+        self._bases()
+        return self._derived[6]
 
     def num_frames(self, L):
         return L // self.hop_length + 1
@@ -149,13 +184,20 @@ class STFT(torch.nn.Module):
         T = self.num_frames(L)
         sym, basisT, _, basisF, _ = self._bases()
         sym = sym and not reference_order
+        fft = None if reference_order else self._fft()
         logmag = torch.empty(B, 1, self.cutoff, T, device=wave.device, dtype=torch.float32)
         # a caller that only needs the magnitudes (the clean target of the spectral loss) skips atan2 and its store
         phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32) if want_phase else None
         absmax = torch.empty(B, device=wave.device, dtype=torch.float32) if return_absmax else None
-        _lib.call("noise_stft_fwd_sym" if sym else "noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisF if sym else basisT), _lib.ptr(logmag), _lib.ptr(phase),
-                  _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream(),
-                  nbytes=4 * B * L + (8 if want_phase else 4) * B * self.cutoff * T)
+        nbytes = 4 * B * L + (8 if want_phase else 4) * B * self.cutoff * T
+        if fft is not None:
+            _lib.call("noise_stft_fwd_fft", _lib.ptr(wave), _lib.ptr(fft[0]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
+                      _lib.ptr(logmag), _lib.ptr(phase), _lib.ptr(absmax), B, L, self.n_fft, self.hop_length,
+                      _lib.stream(), nbytes=nbytes)
+        else:
+            _lib.call("noise_stft_fwd_sym" if sym else "noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisF if sym else basisT),
+                      _lib.ptr(logmag), _lib.ptr(phase), _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream(),
+                      nbytes=nbytes)
         if return_absmax:
             return logmag, phase, absmax
         return logmag, phase
@@ -168,6 +210,12 @@ class STFT(torch.nn.Module):
         n_out = self.hop_length * (T - 1)
         assert self.n_fft + self.hop_length * (T - 1) <= self.window_sum.numel(), "more frames than max_frames"
         out = torch.empty(B, 1, 1, n_out, device=lm.device, dtype=torch.float32)
+        fft = self._fft()
+        if fft is not None:
+            _lib.call("noise_istft_fwd_fft", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(fft[1]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
+                      _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft, self.hop_length,
+                      _lib.stream(), nbytes=8 * B * F * T + 4 * B * n_out)
+            return out
         _lib.call("noise_istft_fwd_sym" if self._bases()[0] else "noise_istft_fwd", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(self.inverse_basis),
                   _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft,
                   self.hop_length, _lib.stream(), nbytes=8 * B * F * T + 4 * B * n_out)
@@ -179,6 +227,13 @@ class STFT(torch.nn.Module):
         g = grad_out.contiguous().float()
         if d_lm is None:
             d_lm = torch.empty_like(log_magnitude, dtype=torch.float32)
+        fft = self._fft()
+        if fft is not None:
+            _lib.call("noise_istft_bwd_fft", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
+                      _lib.ptr(phase.contiguous()), _lib.ptr(fft[1]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
+                      _lib.ptr(self.window_sum), _lib.ptr(d_lm), int(accumulate), B, T, self.n_fft, self.hop_length,
+                      _lib.stream(), nbytes=8 * g.numel() + (12 + 4 * int(accumulate)) * B * F * T)
+            return d_lm
         _lib.call("noise_istft_bwd_sym" if sym else "noise_istft_bwd", _lib.ptr(g), _lib.ptr(out), _lib.ptr(log_magnitude.contiguous()),
                   _lib.ptr(phase.contiguous()), _lib.ptr(inv_basisF if sym else inv_basisT), _lib.ptr(self.window_sum), _lib.ptr(d_lm),
                   int(accumulate), B, T, self.n_fft, self.hop_length, _lib.stream(),

@@ -19,15 +19,19 @@ CONFIGS = [("A", 320, 160), ("B", 512, 128)]
 
 
 def _stft(n_fft, hop, dev, max_frames=1500, sym=True, window="hann", win_length=None):
-    """sym=True: the folded kernels (taken for every symmetric window); sym=False forces the general kernels."""
+    """sym = "fft": the in-LDS FFT kernels (taken whenever the bases are window x DFT and n_fft is 320 or 512);
+    True: the folded dense kernels (every symmetric window); False: the general dense kernels."""
     from noise_amd import STFT
     st = STFT(max_frames, n_fft, hop, win_length or n_fft, window).to(dev)
-    st.use_symmetry = sym
-    assert st._bases()[0] == sym
+    st.use_fft = sym == "fft"
+    st.use_symmetry = bool(sym)
+    assert (st._fft() is not None) == (sym == "fft")
+    if sym != "fft":          # (the FFT kernels do not care whether the window is symmetric)
+        assert st._bases()[0] == bool(sym)
     return st
 
 
-SYM = pytest.mark.parametrize("sym", [True, False], ids=["folded", "general"])
+SYM = pytest.mark.parametrize("sym", ["fft", True, False], ids=["fft", "folded", "general"])
 
 
 @SYM
@@ -125,12 +129,52 @@ def test_folded_equals_general(dev, n_fft, hop, win, window):
     np.testing.assert_allclose(grads[0], grads[1], atol=1e-5 * np.abs(grads[1]).max() + 1e-6)
 
 
+@pytest.mark.parametrize("n_fft,hop,win,window", [(320, 160, 200, "hann"), (320, 160, 320, "hamming"), (512, 128, 512, "blackman"),
+                                                 (512, 256, 400, "hamming"), (320, 80, 320, "hann")])
+def test_fft_equals_general(dev, n_fft, hop, win, window):
+    """Other windows (also asymmetric after centring), short windows padded to n_fft, n_fft/hop = 2 and 4: the FFT
+    kernels agree with the dense general ones in all three directions (forward, inverse, adjoint)."""
+    a = _stft(n_fft, hop, dev, max_frames=200, sym="fft", window=window, win_length=win)
+    b = _stft(n_fft, hop, dev, max_frames=200, sym=False, window=window, win_length=win)
+    g = torch.Generator().manual_seed(n_fft + hop)
+    w = (torch.randn(3, 1, 1, 37 * hop + 11, generator=g) * 0.3).clamp(-1, 1).to(dev)
+    la, pa, ma = a.forward(w, return_absmax=True)
+    lb, pb, mb = b.forward(w, return_absmax=True)
+    Xa = torch.exp(la[:, 0].double()) * torch.exp(1j * pa.double())
+    Xb = torch.exp(lb[:, 0].double()) * torch.exp(1j * pb.double())
+    live = lb[:, 0] > np.log(1e-3) + 1e-6
+    assert (Xa - Xb).abs()[live].max().item() <= 1e-5 * Xb.abs().max().item()
+    # max |log-magnitude| is usually attained on a weak bin, where the logarithm magnifies the (absolute) 1e-5 spectrum
+    # tolerance: compared a little looser than the spectrum itself
+    np.testing.assert_allclose(ma.cpu().numpy(), mb.cpu().numpy(), rtol=1e-4)
+    lm = (lb + 0.2 * torch.randn(lb.shape, generator=g).to(dev))
+    outs, grads = [], []
+    gout = torch.randn(3, 1, 1, hop * (lb.shape[-1] - 1), generator=g).to(dev)
+    for st in (a, b):
+        for acc in (False, True):
+            x = lm.clone().requires_grad_(True)
+            o = st.inverse(x, pb)
+            (o * gout).sum().backward()
+        outs.append(o.detach().cpu().numpy())
+        grads.append(x.grad.cpu().numpy())
+    np.testing.assert_allclose(outs[0], outs[1], atol=1e-5)
+    np.testing.assert_allclose(grads[0], grads[1], atol=1e-5 * np.abs(grads[1]).max() + 1e-6)
+    # the accumulating form of the adjoint (the training step adds the waveform-loss gradient to the spectral one)
+    base = torch.randn_like(lm)
+    d1, d2 = base.clone(), base.clone()
+    a._inverse_bwd(gout, torch.from_numpy(outs[0]).to(dev), lm, pb, d_lm=d1, accumulate=True)
+    b._inverse_bwd(gout, torch.from_numpy(outs[1]).to(dev), lm, pb, d_lm=d2, accumulate=True)
+    np.testing.assert_allclose(d1.cpu().numpy(), d2.cpu().numpy(), atol=1e-5 * np.abs(grads[1]).max() + 1e-5)
+
+
 def test_asymmetric_basis_takes_general_kernels(dev):
     from noise_amd import STFT
     st = _stft(320, 160, dev, max_frames=100)
     with torch.no_grad():
         st.forward_basis[3, 0, 17] += 0.01
     assert st._bases()[0] is False
+    st.use_fft = True
+    assert st._fft() is None          # an edited basis is no longer window x DFT: dense kernels
     # a periodic Hamming window shorter than n_fft: its first sample (0.08) has no mirror partner after centring
     assert STFT(100, 320, 160, 200, "hamming").to(dev)._bases()[0] is False
 
