@@ -219,6 +219,9 @@ int noise_attn_pre_fwd(const float* x_y, const float* x_coef, int x_relu6, const
  * counter-based RNG keyed on (seed, element index) with drop probability p_drop */
 int noise_attn_core_fwd(const float* qkv, float* o, float* ml, const unsigned char* keep, unsigned long long seed,
                         float p_drop, long ntok, int n, int d_model, int heads, int dk, void* stream);
+/* the same core for the bf16 inference path: no dropout, half-precision operands on the matrix cores, fp32 scores and
+ * accumulation, any clip length whose K / V fit LDS (about 2,400 tokens) */
+int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, int n, int d_model, int heads, int dk, void* stream);
 int noise_attn_core_bwd(const float* qkv, const float* d_o, const float* ml, const unsigned char* keep,
                         unsigned long long seed, float p_drop, float* d_qkv, long ntok, int n, int d_model,
                         int heads, int dk, void* stream);

@@ -1,0 +1,132 @@
+// Attention core of the bottleneck Transformer layer for the bf16 inference path, gfx950.
+//
+// softmax((q / sqrt(d_k)) k^T) v per head (train/models.py:27-37, :60-89), no dropout (eval mode), any clip length:
+// half-precision operands on the matrix cores, fp32 scores, online softmax, so the n x n scores are never stored.
+// K and V^T of one (clip, head) live in LDS; a wave owns 16 queries and walks the keys 32 at a time:
+//     S^T [key][query] = K Q^T          two v_mfma_f32_16x16x16_f16 (d_k <= 16 is the reduction index)
+//     running max / rescale / p = exp(s - m)
+//     O^T [d][query] += V^T P^T         one v_mfma_f32_16x16x32_f16 whose 32-deep reduction index is laid out so that
+//                                       the lane's own 8 probabilities are its B fragment (no shuffles): slot j of
+//                                       lane group q is key 4q + j (j < 4) or 16 + 4q + (j - 4)
+#include "common.h"
+
+namespace {
+
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+struct Attn16Dims {
+  long ntok;
+  int n, heads, dk, hd, n32, vp;   // n32 = n rounded up to 32; vp = row pitch of V^T (halves)
+};
+
+__global__ __launch_bounds__(512) void attn_core_f16_kernel(const float* __restrict__ qkv, float* __restrict__ o, Attn16Dims d,
+                                                            int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  _Float16* ks = reinterpret_cast<_Float16*>(lds_raw);   // [n32][16], rows >= n and columns >= d_k zero
+  _Float16* vt = ks + (size_t)d.n32 * 16;                 // [16][vp], V transposed, zero padded
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit;
+  const int b = bh / d.heads, h = bh % d.heads;
+  const long base = (long)b * n;
+  const int nthr = blockDim.x, nw = nthr >> 6;
+  for (int i = threadIdx.x; i < d.n32 * 16; i += nthr) {     // clamped addresses, padding selected afterwards
+    const int j = i >> 4, c = i & 15;
+    const bool in = j < n && c < dk;
+    const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : dk - 1);
+    const float kv = row[d.hd], vv = row[2 * d.hd];
+    ks[i] = (_Float16)(in ? kv : 0.f);
+    vt[c * d.vp + j] = (_Float16)(in ? vv : 0.f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  const float qscale = 1.f / sqrtf((float)dk);
+  const int ntile = (n + 15) >> 4, nblk = d.n32 >> 5;
+  for (int qt = split * nw + wave; qt < ntile; qt += nw * nsplit) {
+    const int qi = qt * 16 + p;
+    const bool valid = qi < n;
+    const float* qrow = qkv + (base + (valid ? qi : n - 1)) * O + h * dk;
+    f16x4 qb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qb[r] = (_Float16)((4 * q + r < dk) ? qrow[4 * q + r] * qscale : 0.f);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int kb = 0; kb < nblk; ++kb) {
+      const int key0 = 32 * kb;
+      const f16x4 ka0 = *reinterpret_cast<const f16x4*>(ks + (key0 + p) * 16 + 4 * q);
+      const f16x4 ka1 = *reinterpret_cast<const f16x4*>(ks + (key0 + 16 + p) * 16 + 4 * q);
+      const f16x4 va0 = *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 4 * q);
+      const f16x4 va1 = *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 16 + 4 * q);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ka0, qb, zero, 0, 0, 0);
+      f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ka1, qb, zero, 0, 0, 0);
+      if (key0 + 32 > n) {      // only the last block holds keys past the clip
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (key0 + 4 * q + r >= n) s0[r] = -INFINITY;
+          if (key0 + 16 + 4 * q + r >= n) s1[r] = -INFINITY;
+        }
+      }
+      float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m, bm);          // finite: every block holds at least one real key
+      const float sc = __expf(m - mn);
+      float pr[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = __expf(s0[r] - mn);
+        pr[4 + r] = __expf(s1[r] - mn);
+      }
+      l = l * sc + (((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] *= sc;
+      f16x8 pb, va;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pb[r] = (_Float16)pr[r];
+        pb[4 + r] = (_Float16)pr[4 + r];
+        va[r] = va0[r];
+        va[4 + r] = va1[r];
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, acc, 0, 0, 0);
+      m = mn;
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (valid) {
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * q + r;
+        if (c < dk) o[(base + qi) * d.hd + h * dk + c] = acc[r] * inv;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// o [ntok][heads*dk] fp32 from qkv [ntok][3*heads*dk] fp32 (q | k | v, head-major), n tokens per clip.
+NOISE_EXPORT int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, int n, int d_model, int heads, int dk,
+                                         void* stream) {
+  NOISE_REQUIRE(qkv && o, "noise_attn_core_fwd_f16: null pointer");
+  NOISE_REQUIRE(heads > 0 && dk > 0 && dk <= 16 && heads * dk <= d_model, "noise_attn_core_fwd_f16: heads=%d d_k=%d unsupported",
+                heads, dk);
+  NOISE_REQUIRE(n > 0 && ntok > 0 && ntok % n == 0, "noise_attn_core_fwd_f16: %ld tokens is not a multiple of n=%d", ntok, n);
+  Attn16Dims d{ntok, n, heads, dk, heads * dk, (n + 31) / 32 * 32, 0};
+  d.vp = d.n32 + 8;
+  const size_t smem = ((size_t)d.n32 * 16 + (size_t)16 * d.vp) * sizeof(_Float16);
+  NOISE_REQUIRE(smem <= 158 * 1024, "noise_attn_core_fwd_f16: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
+  const long bh = (ntok / n) * heads;
+  const int threads = smem > 48 * 1024 ? 512 : 256, nw = threads / 64;
+  int nsplit = (int)(2048 / bh);
+  const int max_split = ((n + 15) / 16 + nw - 1) / nw;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  NOISE_ALLOW_LDS(attn_core_f16_kernel, smem);
+  hipLaunchKernelGGL(attn_core_f16_kernel, dim3((unsigned)(bh * nsplit)), dim3(threads), smem, (hipStream_t)stream, qkv, o, d,
+                     nsplit);
+  NOISE_CHECK_LAUNCH("noise_attn_core_fwd_f16");
+  return 0;
+}

@@ -86,6 +86,7 @@ def ir_block(x, skip, crop, wts, out, transposed):
 
 
 _lib.register({
+    "noise_attn_core_fwd_f16": [_P, _P, ctypes.c_long, _I, _I, _I, _I, _P],
     "noise_fused_head": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "noise_fused_tail": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                          _I, _I, _I, _I, _I, _P],
@@ -222,8 +223,7 @@ class FusedDenoiser:
         _lib.call("noise_attn_pre_fwd", ptr(self.a4), None, 0, ptr(att.layer_norm.weight), ptr(att.layer_norm.bias),
                   ptr(sa.w_qs.weight), ptr(sa.w_ks.weight), ptr(sa.w_vs.weight), ptr(self.xhat0), ptr(self.rstd0),
                   ptr(self.qkv), *dims, st, nbytes=4 * self.ntok * (2 * 64 + 3 * hd))
-        _lib.call("noise_attn_core_fwd", ptr(self.qkv), ptr(self.att_o), None, None, 0, 0.0, *dims, st,
-                  nbytes=4 * self.ntok * 4 * hd)
+        _lib.call("noise_attn_core_fwd_f16", ptr(self.qkv), ptr(self.att_o), *dims, st, nbytes=4 * self.ntok * 4 * hd)
         _lib.call("noise_attn_post_fwd", ptr(self.att_o), ptr(self.xhat0), ptr(att.layer_norm.weight),
                   ptr(att.layer_norm.bias), ptr(sa.fc.weight), ptr(sa.layer_norm.weight), ptr(sa.layer_norm.bias),
                   ptr(ff.w_1.weight), ptr(ff.w_1.bias), ptr(ff.w_2.weight), ptr(ff.w_2.bias), ptr(ff.layer_norm.weight),

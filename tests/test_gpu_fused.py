@@ -141,3 +141,23 @@ def test_fused_forward_vs_oracle(dev, golden_dir, tag, n_fft, hop, L, B, first_L
     # fp32 mode of the same model stays on the per-layer kernels and the tight tolerance
     m.inference_dtype = "fp32"
     np.testing.assert_allclose(m(wd).cpu().numpy(), out_ref.numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("B,n,heads,dk", [(2, 55, 6, 10), (3, 704, 6, 10), (1, 1360, 6, 10), (2, 33, 4, 16), (2, 130, 8, 7),
+                                          (1, 2000, 6, 10)])
+def test_attention_core_f16(dev, B, n, heads, dk):
+    """Half-precision attention core of the bf16 inference path (train/models.py:27-37, eval mode) against torch:
+    tolerance 2e-3 of the largest output (operands carry 11 significant bits, scores and sums are fp32)."""
+    from noise_amd import _lib, fused  # noqa: F401
+    from noise_amd._lib import ptr
+    g = torch.Generator().manual_seed(n)
+    hd = heads * dk
+    qkv = torch.randn(B * n, 3 * hd, generator=g)
+    q, k, v = (t.reshape(B, n, heads, dk).transpose(1, 2) for t in qkv.split(hd, dim=1))
+    att = torch.softmax(torch.matmul(q / dk ** 0.5, k.transpose(2, 3)), dim=-1)
+    ref = torch.matmul(att, v).transpose(1, 2).reshape(B * n, hd)
+    qkv_d = qkv.to(dev)
+    o = torch.full((B * n, hd), float("nan"), device=dev)
+    _lib.call("noise_attn_core_fwd_f16", ptr(qkv_d), ptr(o), B * n, n, 64, heads, dk, _lib.stream())
+    err = ((o.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-3, err
