@@ -41,7 +41,9 @@ def cpu_baseline(seconds_budget=20.0):
     training steps of 128 segments (64 audio-seconds) on the host cores."""
     from oracle import spectral as osp
     from noise_amd.data import synth_batch
-    threads = min(16, os.cpu_count() or 1)
+    # all the host cores this job may use: the GPU box gives a one-GPU job a share of 16 cores of a much larger host and
+    # exports it as OMP_NUM_THREADS (os.cpu_count() would report the whole machine)
+    threads = int(os.environ.get("OMP_NUM_THREADS") or min(16, os.cpu_count() or 1))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = build_model("cpu")
@@ -69,7 +71,8 @@ def cpu_baseline(seconds_budget=20.0):
             break
     # first step is warm-up-ish on CPU as well; report the steady average over all timed steps
     return {"value": round(steps * B * 0.5 / el, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
-            "sample": f"{steps} training steps of {B} x 0.5 s segments (fwd+bwd+AdamW, fp32) on the CPU oracle"}
+            "sample": f"{steps} training steps of {B} x 0.5 s segments (fwd+bwd+AdamW, fp32) on the CPU oracle, torch CPU "
+                      f"kernels on {threads} threads = this job's share of the host's cores (OMP_NUM_THREADS)"}
 
 
 # entry point -> the kernel that moves its bytes (names as rocprofv3 reports them, template arguments dropped)
@@ -78,11 +81,54 @@ MAIN_KERNEL = {"noise_pw_bwd": "pw_bwd_kernel", "noise_pw_fwd": "pw_gemm_kernel"
                "noise_last_convT_fwd": "last_cell_fwd_kernel", "noise_stft_fwd": "stft_frames_kernel"}
 
 
+def measured_peaks():
+    """What this GPU model achieved in the micro-benchmarks of scripts/peaks.py (committed under profiles/): streaming
+    copy / fill rates and MFMA issue rates, quoted next to the spec peak the roofline fraction is priced against."""
+    path = os.path.join(ROOT, "profiles", "r2_measured_peaks.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    d.pop("note", None)
+    return d
+
+
+def other_configs(device):
+    """Short measurements of the other BASELINE configurations on this GPU, reported beside the headline number:
+    configs[1] (256 x 10 s clips, bf16 block-fused inference forward STFT -> denoiser -> iSTFT) at the reference STFT
+    (320/160) and at BASELINE's (512/128), and the same forward in fp32."""
+    from noise_amd import VADSpectralV2
+    from noise_amd.data import synth_batch
+    out = {}
+    B = 256
+    x, _, _ = synth_batch(B, 160000, device, seed=7)
+    x = x.view(B, 1, 1, -1)
+    for tag, n_fft, hop in (("320_160", 320, 160), ("512_128", 512, 128)):
+        torch.manual_seed(0)
+        m = VADSpectralV2(n_fft=n_fft, hop_length=hop, win_length=n_fft, window="hann", nhead=6, num_layers=1, dropout=0.0,
+                          layer_config=[list(r) for r in LAYER_CONFIG], pad_value=-1, max_frames=1300).to(device).eval()
+        for mode in ("bf16", "fp32"):
+            m.inference_dtype = mode
+            with torch.no_grad():
+                for _ in range(2):
+                    m(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    m(x)
+                torch.cuda.synchronize()
+            out[f"infer_{mode}_256x10s_{tag}_audio_s_per_s"] = round(5 * B * 10 / (time.perf_counter() - t0), 1)
+            m.model._plans.clear()
+        del m
+        torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(entry_point, clips=64):
     """HBM bytes per launch of the entry point's main kernel, from the committed PMC passes of this same command
-    (profiles/r1_hbm_traffic_per_kernel.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
+    (profiles/r2_hbm_traffic_per_kernel.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
     FETCH_SIZE doubled as gfx950 requires); None when no such profile is available."""
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r2_hbm_traffic_per_kernel.json")
     kernel = MAIN_KERNEL.get(entry_point)
     if kernel is None or clips != 64 or not os.path.exists(path):   # the passes were taken on the default workload
         return None
@@ -98,6 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clips", type=int, default=64, help="10 s clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short inference measurements")
     ap.add_argument("--breakdown", action="store_true", help="print the per-entry-point table to stderr")
     ap.add_argument("--all-events", action="store_true", help="(diagnostic) instrument every call in the timed region too")
     args = ap.parse_args()
@@ -184,7 +231,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(dbytes / dn),
                 "launches_per_step": dn // args.steps, "avg_launch_ms": round(dms / dn, 4),
                 "share_of_step": round(dms / args.steps / step_ms, 3),
-                "step_hbm_frac": round(step_bytes / 1e6 / step_ms / HBM_PEAK_GBS, 4)}
+                "step_hbm_frac": round(step_bytes / 1e6 / step_ms / HBM_PEAK_GBS, 4),
+                "measured_peaks": measured_peaks()}
 
     if rank == 0:
         line = {
@@ -198,6 +246,10 @@ def main():
                        "parallelism": f"dp{world}", "loss": round(loss, 5)},
             "roofline": roofline,
         }
+        if not args.no_other_configs and world == 1:
+            del model, opt, noisy, clean
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(device)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

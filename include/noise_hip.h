@@ -262,6 +262,13 @@ int noise_loss_finalize(const double* spec_partial, int n_spec, long spec_count,
 int noise_adamw_step(float* p, const float* g, float* m, float* v, long long* step, long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* ---- micro-benchmarks of the two rooflines (no counterpart in the reference; not on the product path) ----------- */
+/* dst = src (n floats, n % 4 == 0): 8 * n bytes of HBM traffic */
+int noise_bench_copy(const float* src, float* dst, long n, void* stream);
+/* back-to-back MFMA issue: kind 0 = v_mfma_f32_16x16x4_f32 (2048 flop per wave instruction), kind 1 =
+ * v_mfma_f32_16x16x32_f16 (16384 flop); blocks x 4 waves x iters x 4 instructions; out: blocks * 256 floats */
+int noise_bench_mfma(int kind, float* out, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

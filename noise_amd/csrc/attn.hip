@@ -475,7 +475,10 @@ __global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __r
   extern __shared__ float lds[];
   constexpr int DKP = DK4 * 4;
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
-  const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+  // the heads of a clip read the same token rows (40-byte pieces of 720-byte rows): they are placed on one XCD
+  const int vblk = xcd_chunked_block();
+  if (vblk >= (int)(d.ntok / n) * d.heads) return;
+  const int b = vblk / d.heads, h = vblk % d.heads;
   float* ks = lds;             // [n][DKP]
   float* vs = ks + n * DKP;    // [n][DKP]
   const long base = (long)b * n;
@@ -532,7 +535,9 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
   extern __shared__ float lds[];
   constexpr int DKP = DK4 * 4;
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
-  const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+  const int vblk = xcd_chunked_block();      // see attn_core_fwd_wave_kernel
+  if (vblk >= (int)(d.ntok / n) * d.heads) return;
+  const int b = vblk / d.heads, h = vblk % d.heads;
   const int mp = n | 1;            // odd pitch: row-wise writes and column-wise reads are both conflict-free
   float* qs = lds;                 // [n][DKP], already divided by the temperature
   float* ks = qs + n * DKP;
@@ -1090,7 +1095,7 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
   if (n <= AW) {   // one wave per (clip, head)
     const int dk4 = (dk + 3) / 4;
     const size_t sm = (size_t)2 * n * dk4 * 4 * sizeof(float);
-    const dim3 grid((unsigned)(ntok / n) * heads);
+    const dim3 grid((unsigned)noise_pad8((ntok / n) * heads));
     const int drop = keep ? 1 : (p_drop > 0.f ? 2 : 0);
 #define X(K4)                                                                                                     \
   if (dk4 == K4) {                                                                                                \
@@ -1147,7 +1152,7 @@ NOISE_EXPORT int noise_attn_core_bwd(const float* qkv, const float* d_o, const f
   if (n <= AW) {   // one wave per (clip, head)
     const int dk4 = (dk + 3) / 4;
     const size_t sm = (size_t)(4 * n * dk4 * 4 + n * (n | 1)) * sizeof(float);
-    const dim3 grid((unsigned)(ntok / n) * heads);
+    const dim3 grid((unsigned)noise_pad8((ntok / n) * heads));
     const int drop = keep ? 1 : (p_drop > 0.f ? 2 : 0);
 #define X(K4)                                                                                                        \
   if (dk4 == K4) {                                                                                                   \

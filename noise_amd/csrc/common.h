@@ -37,6 +37,7 @@ void noise_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int noise_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int noise_pad8(long n) { return (int)((n + 7) / 8 * 8); }   // grid size for xcd_chunked_block()
 
 // Memory-bound elementwise/reduction kernels: cap the grid and grid-stride the rest.
 static inline int noise_grid(long work_items, int per_block, int cap = 2048) {
@@ -109,6 +110,13 @@ struct BwdEpilogue {
 #ifdef __HIPCC__
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Workgroups are dealt round-robin over the 8 XCDs (observed behaviour, used for L2 locality only, never for
+// correctness): blocks b and b + 8 share an L2.  With a grid that is a multiple of 8 this maps blockIdx.x to a virtual
+// index such that CONSECUTIVE virtual indices run on the same XCD, so neighbours that read the same cache lines fetch
+// them from HBM once instead of once per XCD.  The launcher pads the grid to a multiple of 8; padding blocks get an
+// index >= the real count and return at once.
+__device__ __forceinline__ int xcd_chunked_block() { return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
 
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 

@@ -244,8 +244,12 @@ __device__ __forceinline__ void bitonic_sort_row(float (&v)[EPT], float* xch, in
 
 template <int EPT>
 __global__ __launch_bounds__(256, 2) void wave_pair_rows_kernel(const float* __restrict__ w, const float* __restrict__ c,
-                                                             int B, int L, float scale, float* __restrict__ d_w,
-                                                             double* __restrict__ partial) {
+                                                             int B, int L, int ntiles, float scale,
+                                                             float* __restrict__ d_w, double* __restrict__ partial) {
+  // a tile reads 16 bytes of every clip row: eight neighbouring tiles share each 128-byte line, so neighbours are placed
+  // on one XCD (without this every line was fetched by up to 8 L2s: 6x the algorithmic traffic)
+  const int vblk = xcd_chunked_block();
+  if (vblk >= ntiles) return;
   constexpr int NP = 256 * EPT, R = EPT;   // R: clips per thread (B <= NP)
   extern __shared__ double lds_d[];
   double* P = lds_d;                                   // [B + 1] prefix sums of the sorted row
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void wave_pair_rows_kernel(const float* __r
   __shared__ double red[4], wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pitch = B | 1;
-  const int t0 = blockIdx.x * RT;
+  const int t0 = vblk * RT;
   const bool vec = (L & 3) == 0 && t0 + RT <= L;       // whole, 16-byte aligned pieces
 
   constexpr int Q = RT / 4;   // float4 pieces per clip
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void wave_pair_rows_kernel(const float* __r
     }
   }
   total = block_sum_d(total, red);
-  if (tid == 0) partial[blockIdx.x] = total;
+  if (tid == 0) partial[vblk] = total;
 }
 
 // out[0..3] = loss, vad_loss, waveform_loss, spectral_loss;  d_vad[b] = (sigmoid(x) - y)/B
@@ -477,8 +481,8 @@ NOISE_EXPORT int noise_wave_pair_l1(const float* wave, const float* clean, float
 #define ROWS(ept)                                                                                                  \
   do {                                                                                                             \
     NOISE_ALLOW_LDS(wave_pair_rows_kernel<ept>, smem);                                                             \
-    hipLaunchKernelGGL(wave_pair_rows_kernel<ept>, dim3(grid), dim3(256), smem, st, wave, clean, B, L, scale,      \
-                       d_wave, partial);                                                                           \
+    hipLaunchKernelGGL(wave_pair_rows_kernel<ept>, dim3(noise_pad8(grid)), dim3(256), smem, st, wave, clean, B, L,  \
+                       grid, scale, d_wave, partial);                                                                       \
   } while (0)
       if (NP == 256) ROWS(1);
       else if (NP == 512) ROWS(2);
