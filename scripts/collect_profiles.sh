@@ -1,0 +1,16 @@
+#!/bin/bash
+# Copy the summaries written by scripts/profile_round.sh (gpurun_out/prof) into profiles/, named per round.
+R=${1:-r2}
+P=gpurun_out/prof
+cp $P/bench_line.json profiles/${R}_bench_line.json
+cp $P/entry_point_breakdown.txt profiles/${R}_entry_point_breakdown.txt
+cp $P/kt/p_kernel_stats.csv profiles/${R}_train_step_kernel_stats.csv
+cp $P/hbm_traffic.txt profiles/${R}_hbm_traffic.txt
+cp $P/hbm_traffic_per_kernel.json profiles/${R}_hbm_traffic_per_kernel.json
+cp $P/mfma_utilisation.txt profiles/${R}_mfma_utilisation.txt
+cp $P/infer_A.txt profiles/${R}_infer_320_160.txt
+cp $P/infer_B.txt profiles/${R}_infer_512_128.txt
+cp $P/ikt/p_kernel_stats.csv profiles/${R}_infer_bf16_kernel_stats.csv
+cp $P/infer_hbm_traffic.txt profiles/${R}_infer_bf16_hbm_traffic.txt
+cp $P/infer_hbm_traffic_per_kernel.json profiles/${R}_infer_bf16_hbm_traffic_per_kernel.json
+cp $P/infer_mfma_utilisation.txt profiles/${R}_infer_bf16_mfma_utilisation.txt
