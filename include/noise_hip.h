@@ -74,6 +74,25 @@ int noise_istft_bwd_fft(const float* d_wave, const float* wave_out, const float*
                         const float* syn_window, const float* tw1, const float* tw2, const float* window_sum,
                         float* d_logmag, int accumulate, int B, int T, int n_fft, int hop, void* stream);
 
+/* ---- loss of the waveform models (train/models.py:641-720) ------------------------------------------------------ */
+/* One resolution of Base.multi_resolution_stft_loss (:700-720) with Base.stft_mag (:687-698): torch.stft semantics
+ * (reflect-padded centred frames, T = 1 + L/hop, window of win_length samples centred in n_fft), magnitudes clamped at
+ * sqrt(1e-7), loss[0] (+)= mean |log mag(clean) - log mag(enhanced)|; d_enhanced (+)= grad_scale * d loss / d enhanced.
+ * window [n_fft] is the padded window; tw1 [n_fft/2][2] = e^{-2 pi i j/(n_fft/2)}, tw2 [n_fft/2+1][2] = e^{-2 pi i k/n_fft}.
+ * Workspaces: frame_grad [B][T][win_length] floats (NULL together with d_enhanced: loss only), partial
+ * noise_mrstft_partials() doubles.  Serves n_fft 512, 1024, 2048 (the sizes of the reference's configs). */
+int noise_mrstft_supported(int n_fft);
+int noise_mrstft_partials(int B, int L, int n_fft, int hop);
+int noise_mrstft_term(const float* enhanced, const float* clean, const float* window, const float* tw1, const float* tw2,
+                      float grad_scale, float* frame_grad, double* partial, double* loss, int accumulate_loss,
+                      float* d_enhanced, int accumulate_grad, int B, int L, int n_fft, int hop, int win_length,
+                      void* stream);
+/* F.smooth_l1_loss(x, y, beta) as :657 calls it (mean): loss[0] (+)= value, d_x (+)= grad_scale * gradient (d_x may be
+ * NULL); partial: noise_smooth_l1_blocks() doubles. */
+int noise_smooth_l1_blocks(void);
+int noise_smooth_l1(const float* x, const float* y, long n, float beta, float grad_scale, double* partial, double* loss,
+                    int accumulate_loss, float* d_x, int accumulate_grad, void* stream);
+
 /* ---- deferred folds of per-workgroup slabs (no counterpart in the reference: ATen reduces inside each op) ------ */
 /* out[j] = sum over rows of slab[row*row_stride + j], j < ncols; with tr_k > 0 column j = k*tr_C + c goes to
  * out[c*tr_k + k] (the (C, k) layout of a depthwise weight).  noise_pw_bwd and noise_dw3x3_bwd called with dw = NULL

@@ -245,6 +245,58 @@ def train_fixture(models, path, last_scale):
     np.savez(path, **g3)
 
 
+def mrstft_fixture(models, path):
+    """G5: multi-resolution STFT loss of the waveform models (Base.stft_mag / Base.multi_resolution_stft_loss),
+    called unbound on a stand-in that carries only the hyper-parameters the two methods read."""
+    import torch.nn.functional as F
+    g5 = {}
+    cfg = dict(fft_sizes=[512, 1024, 2048], hop_lengths=[50, 120, 240], win_lengths=[240, 600, 1200])
+
+    def stand_in(**hp):
+        ns = types.SimpleNamespace(hparams=types.SimpleNamespace(**hp))
+        ns.stft_mag = lambda *a: models.Base.stft_mag(ns, *a)
+        return ns
+
+    B, L = 3, 8000
+    clean = _wave(40, (B, 1, 1, L), std=0.05)
+    clean[1, ..., 3000:] = 0.0            # digital silence: magnitudes on the clamp of stft_mag
+    enhanced = (clean + _wave(41, (B, 1, 1, L), std=0.02)).clamp(-1, 1)
+    enhanced[1, ..., 5000:] = 0.0         # both signals silent: clamp active on both sides
+    x = enhanced.clone().requires_grad_(True)
+    ns = stand_in(**cfg)
+    loss = models.Base.multi_resolution_stft_loss(ns, x, clean)
+    loss.backward()
+    g5["enhanced"], g5["clean"] = _np(enhanced), _np(clean)
+    g5["loss"], g5["grad"] = _np(loss), _np(x.grad)
+    for i, (n, h, w) in enumerate(zip(cfg["fft_sizes"], cfg["hop_lengths"], cfg["win_lengths"])):
+        one = stand_in(fft_sizes=[n], hop_lengths=[h], win_lengths=[w])
+        xi = enhanced.clone().requires_grad_(True)
+        li = models.Base.multi_resolution_stft_loss(one, xi, clean)
+        li.backward()
+        g5[f"loss_{i}"], g5[f"grad_{i}"] = _np(li), _np(xi.grad)
+        mag = models.Base.stft_mag(one, enhanced.view(-1, L), n, h, w)       # [B][T][F]
+        g5[f"mag_{i}_shape"] = np.array(mag.shape, dtype=np.int64)
+        g5[f"mag_{i}_frames"] = np.array([0, 1, mag.shape[1] // 2, mag.shape[1] - 1], dtype=np.int64)
+        g5[f"mag_{i}"] = _np(mag[:, g5[f"mag_{i}_frames"], :])
+    # an odd length and a resolution whose hop does not divide anything in sight
+    L2 = 7777
+    c2 = _wave(42, (2, 1, 1, L2), std=0.05)
+    e2 = (c2 + _wave(43, (2, 1, 1, L2), std=0.02)).clamp(-1, 1).requires_grad_(True)
+    l2 = models.Base.multi_resolution_stft_loss(ns, e2, c2)
+    l2.backward()
+    g5["odd_enhanced"], g5["odd_clean"], g5["odd_loss"], g5["odd_grad"] = _np(e2), _np(c2), _np(l2), _np(e2.grad)
+    # the waveform models' training loss (models.py:650-665) on the same tensors, composed exactly as _shared_step does
+    lam = 0.5
+    vad_logit = torch.tensor([0.3, -1.2, 2.0])
+    xt = enhanced.clone().requires_grad_(True)
+    vad_loss = F.binary_cross_entropy_with_logits(vad_logit, ((clean.abs() > 0).sum(dim=-1) >= 160).float().squeeze())
+    l1 = F.smooth_l1_loss(xt, clean, beta=0.5)
+    total = l1 + lam * models.Base.multi_resolution_stft_loss(ns, xt, clean) + vad_loss
+    total.backward()
+    g5["total_lambda"], g5["total_vad_logit"] = np.float32(lam), _np(vad_logit)
+    g5["total_loss"], g5["total_l1"], g5["total_vad"], g5["total_grad"] = _np(total), _np(l1), _np(vad_loss), _np(xt.grad)
+    np.savez(path, **g5)
+
 
 def main():
     _install_standins()
@@ -252,6 +304,10 @@ def main():
     sys.path.insert(0, os.path.join(REF, "process"))
     import models  # noqa: the reference, untouched
     import audiolib  # noqa
+
+    if "--only-g5" in sys.argv:         # the other fixtures stay as committed
+        mrstft_fixture(models, os.path.join(OUT, "g5_mrstft.npz"))
+        return
 
     # ------------------------------------------------------------------ G1: STFT fwd / inv
     g1 = {}
@@ -340,6 +396,9 @@ def main():
         g4[f"case{i}_activity_noisy"] = np.float64(audiolib.activitydetector(y2.copy()))
         g4[f"case{i}_clipped"] = np.int64(bool(audiolib.is_clipped(y2)))
     np.savez(os.path.join(OUT, "g4_mixer.npz"), **g4)
+
+    # ------------------------------------------------------------------ G5: multi-resolution STFT loss
+    mrstft_fixture(models, os.path.join(OUT, "g5_mrstft.npz"))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:32s} {os.path.getsize(os.path.join(OUT, f)):>9d} B")
