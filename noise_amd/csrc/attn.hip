@@ -230,60 +230,107 @@ __device__ __forceinline__ bool keep_elem(const unsigned char* keep, unsigned lo
 }
 
 constexpr int DKMAX = 16;
+constexpr int ATTN_CHUNK_FLOATS = 6144;   // per staged array: two of them + three per-token vectors stay under 64 KiB up to n ~ 1300
+
+// Clips of any length: the rows the inner loops walk (keys and values for a query thread, queries and output
+// gradients for a key thread) pass through LDS in chunks of `kc` rows, padded to a multiple of 4 floats so a row is
+// read with 128-bit broadcasts.  The order of every sum is the plain ascending one whatever the chunk size.
+__device__ __forceinline__ int attn_chunk_rows(int n, int dk) {
+  const int dkp = (dk + 3) & ~3, kc = ATTN_CHUNK_FLOATS / dkp;
+  return n < kc ? n : kc;
+}
+
+// dst[j][c] = src[(row0 + j) * ld + col + c] / div for j < cnt, c < dk; zero for the padding columns.  Barriers on
+// both sides: every thread of the workgroup must call it.
+__device__ __forceinline__ void attn_stage(float* dst, const float* __restrict__ src, long row0, int cnt, int ld, int col,
+                                           int dk, int dkp, float div) {
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < cnt * dkp; idx += 256) {
+    const int j = idx / dkp, c = idx - j * dkp;
+    dst[idx] = c < dk ? src[(row0 + j) * ld + col + c] / div : 0.f;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float attn_dot(const float (&a)[DKMAX], const float* row, int dk4) {
+  float s = 0.f;
+#pragma unroll
+  for (int c4 = 0; c4 < DKMAX / 4; ++c4)
+    if (c4 < dk4) {
+      const float4 r = *reinterpret_cast<const float4*>(row + 4 * c4);
+      s = fmaf(a[4 * c4 + 3], r.w, fmaf(a[4 * c4 + 2], r.z, fmaf(a[4 * c4 + 1], r.y, fmaf(a[4 * c4], r.x, s))));
+    }
+  return s;
+}
+
+__device__ __forceinline__ void attn_axpy(float (&acc)[DKMAX], float a, const float* row, int dk4) {
+#pragma unroll
+  for (int c4 = 0; c4 < DKMAX / 4; ++c4)
+    if (c4 < dk4) {
+      const float4 r = *reinterpret_cast<const float4*>(row + 4 * c4);
+      acc[4 * c4] = fmaf(a, r.x, acc[4 * c4]);
+      acc[4 * c4 + 1] = fmaf(a, r.y, acc[4 * c4 + 1]);
+      acc[4 * c4 + 2] = fmaf(a, r.z, acc[4 * c4 + 2]);
+      acc[4 * c4 + 3] = fmaf(a, r.w, acc[4 * c4 + 3]);
+    }
+}
 
 __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                             float* __restrict__ ml, const unsigned char* __restrict__ keep,
                                                             unsigned long long seed, float p_drop, AttnDims d) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int dk4 = (dk + 3) >> 2, dkp = 4 * dk4, kc = attn_chunk_rows(n, dk);
+  const bool one_chunk = kc >= n;
   const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
-  float* ks = lds;            // [n][dk]
-  float* vs = ks + n * dk;    // [n][dk]
+  float* ks = lds;              // [kc][dkp]
+  float* vs = ks + kc * dkp;    // [kc][dkp]
   const long base = (long)b * n;
-  for (int i = threadIdx.x; i < n * dk; i += 256) {
-    const int j = i / dk, c = i - j * dk;
-    ks[i] = qkv[(base + j) * O + d.hd + h * dk + c];
-    vs[i] = qkv[(base + j) * O + 2 * d.hd + h * dk + c];
-  }
-  __syncthreads();
   const float temp = sqrtf((float)dk);
   const float inv_keep = 1.f / (1.f - p_drop);
-  for (int i = threadIdx.x; i < n; i += 256) {
+  if (one_chunk) {
+    attn_stage(ks, qkv, base, n, O, d.hd + h * dk, dk, dkp, 1.f);
+    attn_stage(vs, qkv, base, n, O, 2 * d.hd + h * dk, dk, dkp, 1.f);
+  }
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const bool act = i < n;
     float q[DKMAX];
 #pragma unroll
-    for (int c = 0; c < DKMAX; ++c) q[c] = c < dk ? qkv[(base + i) * O + h * dk + c] / temp : 0.f;
+    for (int c = 0; c < DKMAX; ++c) q[c] = (act && c < dk) ? qkv[(base + i) * O + h * dk + c] / temp : 0.f;
     float m = -INFINITY;
-    for (int j = 0; j < n; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < DKMAX; ++c)
-        if (c < dk) s = fmaf(q[c], ks[j * dk + c], s);
-      m = fmaxf(m, s);
+    for (int c0 = 0; c0 < n; c0 += kc) {
+      const int cnt = min(kc, n - c0);
+      if (!one_chunk) attn_stage(ks, qkv, base + c0, cnt, O, d.hd + h * dk, dk, dkp, 1.f);
+      if (act)
+        for (int j = 0; j < cnt; ++j) m = fmaxf(m, attn_dot(q, ks + j * dkp, dk4));
     }
     float l = 0.f, acc[DKMAX];
 #pragma unroll
     for (int c = 0; c < DKMAX; ++c) acc[c] = 0.f;
     const long mrow = (((long)b * d.heads + h) * n + i) * n;
-    for (int j = 0; j < n; ++j) {
-      float s = 0.f;
+    for (int c0 = 0; c0 < n; c0 += kc) {
+      const int cnt = min(kc, n - c0);
+      if (!one_chunk) {
+        attn_stage(ks, qkv, base + c0, cnt, O, d.hd + h * dk, dk, dkp, 1.f);
+        attn_stage(vs, qkv, base + c0, cnt, O, 2 * d.hd + h * dk, dk, dkp, 1.f);
+      }
+      if (act)
+        for (int j = 0; j < cnt; ++j) {
+          const float e = expf(attn_dot(q, ks + j * dkp, dk4) - m);
+          l += e;
+          if (keep_elem(keep, seed, p_drop, mrow + c0 + j)) attn_axpy(acc, e, vs + j * dkp, dk4);
+        }
+    }
+    if (act) {
+      const float sc = inv_keep / l;
 #pragma unroll
       for (int c = 0; c < DKMAX; ++c)
-        if (c < dk) s = fmaf(q[c], ks[j * dk + c], s);
-      const float e = expf(s - m);
-      l += e;
-      if (keep_elem(keep, seed, p_drop, mrow + j)) {
-#pragma unroll
-        for (int c = 0; c < DKMAX; ++c)
-          if (c < dk) acc[c] = fmaf(e, vs[j * dk + c], acc[c]);
+        if (c < dk) o[(base + i) * d.hd + h * dk + c] = acc[c] * sc;
+      if (ml) {
+        ml[(((long)b * d.heads + h) * n + i) * 2] = m;
+        ml[(((long)b * d.heads + h) * n + i) * 2 + 1] = l;
       }
-    }
-    const float sc = inv_keep / l;
-#pragma unroll
-    for (int c = 0; c < DKMAX; ++c)
-      if (c < dk) o[(base + i) * d.hd + h * dk + c] = acc[c] * sc;
-    if (ml) {
-      ml[(((long)b * d.heads + h) * n + i) * 2] = m;
-      ml[(((long)b * d.heads + h) * n + i) * 2 + 1] = l;
     }
   }
 }
@@ -293,92 +340,124 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* __restr
                                                             const float* __restrict__ ml, const unsigned char* __restrict__ keep,
                                                             unsigned long long seed, float p_drop, float* __restrict__ d_qkv,
                                                             AttnDims d) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int dk4 = (dk + 3) >> 2, dkp = 4 * dk4, kc = attn_chunk_rows(n, dk);
+  const bool one_chunk = kc >= n;
   const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
-  float* qs = lds;              // [n][dk]  (already divided by the temperature)
-  float* ks = qs + n * dk;
-  float* vs = ks + n * dk;
-  float* dos = vs + n * dk;     // [n][dk]
-  float* mm = dos + n * dk;     // [n] max
+  float* sa = lds;              // [kc][dkp]  keys, then queries (divided by the temperature)
+  float* sb = sa + kc * dkp;    // [kc][dkp]  values, then output gradients
+  float* mm = sb + kc * dkp;    // [n] max
   float* ll = mm + n;           // [n] 1/l
   float* Dd = ll + n;           // [n] D_i
   const long base = (long)b * n;
   const float temp = sqrtf((float)dk);
   const float inv_keep = 1.f / (1.f - p_drop);
-  for (int i = threadIdx.x; i < n * dk; i += 256) {
-    const int j = i / dk, c = i - j * dk;
-    qs[i] = qkv[(base + j) * O + h * dk + c] / temp;
-    ks[i] = qkv[(base + j) * O + d.hd + h * dk + c];
-    vs[i] = qkv[(base + j) * O + 2 * d.hd + h * dk + c];
-    dos[i] = d_o[(base + j) * d.hd + h * dk + c];
-  }
   for (int i = threadIdx.x; i < n; i += 256) {
     mm[i] = ml[(((long)b * d.heads + h) * n + i) * 2];
     ll[i] = 1.f / ml[(((long)b * d.heads + h) * n + i) * 2 + 1];
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const long mrow = (((long)b * d.heads + h) * n + i) * n;
-    float Di = 0.f;
-    for (int j = 0; j < n; ++j) {
-      float s = 0.f, dp = 0.f;
-      for (int c = 0; c < dk; ++c) {
-        s = fmaf(qs[i * dk + c], ks[j * dk + c], s);
-        dp = fmaf(dos[i * dk + c], vs[j * dk + c], dp);
-      }
-      if (!keep_elem(keep, seed, p_drop, mrow + j)) dp = 0.f;
-      Di = fmaf(expf(s - mm[i]) * ll[i], dp * inv_keep, Di);
+  const int kcol = d.hd + h * dk, vcol = 2 * d.hd + h * dk;
+  if (one_chunk) {
+    attn_stage(sa, qkv, base, n, O, kcol, dk, dkp, 1.f);
+    attn_stage(sb, qkv, base, n, O, vcol, dk, dkp, 1.f);
+  }
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const bool act = i < n;
+    const int ic = act ? i : n - 1;
+    float q[DKMAX], go[DKMAX];
+#pragma unroll
+    for (int c = 0; c < DKMAX; ++c) {
+      q[c] = (act && c < dk) ? qkv[(base + i) * O + h * dk + c] / temp : 0.f;
+      go[c] = (act && c < dk) ? d_o[(base + i) * d.hd + h * dk + c] : 0.f;
     }
-    Dd[i] = Di;
+    const long mrow = (((long)b * d.heads + h) * n + ic) * n;
+    float Di = 0.f;
+    for (int c0 = 0; c0 < n; c0 += kc) {
+      const int cnt = min(kc, n - c0);
+      if (!one_chunk) {
+        attn_stage(sa, qkv, base + c0, cnt, O, kcol, dk, dkp, 1.f);
+        attn_stage(sb, qkv, base + c0, cnt, O, vcol, dk, dkp, 1.f);
+      }
+      if (act) {
+        const float mi = mm[i], li = ll[i];
+        for (int j = 0; j < cnt; ++j) {
+          const float sc = attn_dot(q, sa + j * dkp, dk4);
+          float dp = attn_dot(go, sb + j * dkp, dk4);
+          if (!keep_elem(keep, seed, p_drop, mrow + c0 + j)) dp = 0.f;
+          Di = fmaf(expf(sc - mi) * li, dp * inv_keep, Di);
+        }
+      }
+    }
     float dq[DKMAX];
 #pragma unroll
     for (int c = 0; c < DKMAX; ++c) dq[c] = 0.f;
-    for (int j = 0; j < n; ++j) {
-      float s = 0.f, dp = 0.f;
-      for (int c = 0; c < dk; ++c) {
-        s = fmaf(qs[i * dk + c], ks[j * dk + c], s);
-        dp = fmaf(dos[i * dk + c], vs[j * dk + c], dp);
+    for (int c0 = 0; c0 < n; c0 += kc) {
+      const int cnt = min(kc, n - c0);
+      if (!one_chunk) {
+        attn_stage(sa, qkv, base + c0, cnt, O, kcol, dk, dkp, 1.f);
+        attn_stage(sb, qkv, base + c0, cnt, O, vcol, dk, dkp, 1.f);
       }
-      if (!keep_elem(keep, seed, p_drop, mrow + j)) dp = 0.f;
-      const float p = expf(s - mm[i]) * ll[i];
-      const float ds = p * (dp * inv_keep - Di);
+      if (act) {
+        const float mi = mm[i], li = ll[i];
+        for (int j = 0; j < cnt; ++j) {
+          const float sc = attn_dot(q, sa + j * dkp, dk4);
+          float dp = attn_dot(go, sb + j * dkp, dk4);
+          if (!keep_elem(keep, seed, p_drop, mrow + c0 + j)) dp = 0.f;
+          const float p = expf(sc - mi) * li;
+          attn_axpy(dq, p * (dp * inv_keep - Di), sa + j * dkp, dk4);
+        }
+      }
+    }
+    if (act) {
+      Dd[i] = Di;
 #pragma unroll
       for (int c = 0; c < DKMAX; ++c)
-        if (c < dk) dq[c] = fmaf(ds, ks[j * dk + c], dq[c]);
+        if (c < dk) d_qkv[(base + i) * O + h * dk + c] = dq[c] / temp;
     }
-#pragma unroll
-    for (int c = 0; c < DKMAX; ++c)
-      if (c < dk) d_qkv[(base + i) * O + h * dk + c] = dq[c] / temp;
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += 256) {
-    float dkk[DKMAX], dvv[DKMAX];
+  if (one_chunk) {
+    attn_stage(sa, qkv, base, n, O, h * dk, dk, dkp, temp);
+    attn_stage(sb, d_o, base, n, d.hd, h * dk, dk, dkp, 1.f);
+  } else {
+    __syncthreads();      // Dd complete before any key thread reads it
+  }
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    const bool act = j < n;
+    float kr[DKMAX], vr[DKMAX], dkk[DKMAX], dvv[DKMAX];
 #pragma unroll
-    for (int c = 0; c < DKMAX; ++c) dkk[c] = dvv[c] = 0.f;
-    for (int i = 0; i < n; ++i) {
-      float s = 0.f, dp = 0.f;
-      for (int c = 0; c < dk; ++c) {
-        s = fmaf(qs[i * dk + c], ks[j * dk + c], s);
-        dp = fmaf(dos[i * dk + c], vs[j * dk + c], dp);
+    for (int c = 0; c < DKMAX; ++c) {
+      kr[c] = (act && c < dk) ? qkv[(base + j) * O + kcol + c] : 0.f;
+      vr[c] = (act && c < dk) ? qkv[(base + j) * O + vcol + c] : 0.f;
+      dkk[c] = dvv[c] = 0.f;
+    }
+    for (int c0 = 0; c0 < n; c0 += kc) {
+      const int cnt = min(kc, n - c0);
+      if (!one_chunk) {
+        attn_stage(sa, qkv, base + c0, cnt, O, h * dk, dk, dkp, temp);
+        attn_stage(sb, d_o, base + c0, cnt, d.hd, h * dk, dk, dkp, 1.f);
       }
-      const bool kp = keep_elem(keep, seed, p_drop, (((long)b * d.heads + h) * n + i) * n + j);
-      const float p = expf(s - mm[i]) * ll[i];
-      const float pk = kp ? p * inv_keep : 0.f;
-      const float ds = p * ((kp ? dp * inv_keep : 0.f) - Dd[i]);
+      if (act)
+        for (int ii = 0; ii < cnt; ++ii) {
+          const int i = c0 + ii;
+          const float sc = attn_dot(kr, sa + ii * dkp, dk4);
+          const float dp = attn_dot(vr, sb + ii * dkp, dk4);
+          const bool kp = keep_elem(keep, seed, p_drop, (((long)b * d.heads + h) * n + i) * n + j);
+          const float p = expf(sc - mm[i]) * ll[i];
+          attn_axpy(dkk, p * ((kp ? dp * inv_keep : 0.f) - Dd[i]), sa + ii * dkp, dk4);
+          attn_axpy(dvv, kp ? p * inv_keep : 0.f, sb + ii * dkp, dk4);
+        }
+    }
+    if (act) {
 #pragma unroll
       for (int c = 0; c < DKMAX; ++c)
         if (c < dk) {
-          dkk[c] = fmaf(ds, qs[i * dk + c], dkk[c]);
-          dvv[c] = fmaf(pk, dos[i * dk + c], dvv[c]);
+          d_qkv[(base + j) * O + kcol + c] = dkk[c];
+          d_qkv[(base + j) * O + vcol + c] = dvv[c];
         }
     }
-#pragma unroll
-    for (int c = 0; c < DKMAX; ++c)
-      if (c < dk) {
-        d_qkv[(base + j) * O + d.hd + h * dk + c] = dkk[c];
-        d_qkv[(base + j) * O + 2 * d.hd + h * dk + c] = dvv[c];
-      }
   }
 }
 
@@ -1062,6 +1141,11 @@ int check_attn(const char* who, long ntok, int n, int d_model, int heads, int dk
 
 constexpr int ATTN_MAX_BLOCKS = 256;
 
+int attn_chunk_rows_host(int n, int dk) {
+  const int kc = ATTN_CHUNK_FLOATS / ((dk + 3) / 4 * 4);
+  return n < kc ? n : kc;
+}
+
 }  // namespace
 
 NOISE_EXPORT int noise_attn_max_blocks(void) { return ATTN_MAX_BLOCKS; }
@@ -1114,10 +1198,10 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
     NOISE_CHECK_LAUNCH("noise_attn_core_fwd/wave");
     return 0;
   }
-  if (keep == nullptr && p_drop == 0.f) {   // no dropout: MFMA tiles with an online softmax
+  const size_t sm_mfma = (size_t)(2 * ((n + 15) / 16 * 16) + 1) * ((dk + 3) / 4) * 4 * sizeof(float);
+  if (keep == nullptr && p_drop == 0.f && sm_mfma <= 158 * 1024) {   // no dropout: MFMA tiles with an online softmax
     const int dk4 = (dk + 3) / 4, n16 = (n + 15) / 16 * 16;
-    const size_t sm = (size_t)(2 * n16 + 1) * dk4 * 4 * sizeof(float);
-    NOISE_REQUIRE(sm <= 158 * 1024, "noise_attn_core_fwd: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
+    const size_t sm = sm_mfma;
     const long bh = (ntok / n) * heads;
     int nsplit = (int)(1024 / bh);
     const int max_split = (n16 / 16 + 3) / 4;
@@ -1134,8 +1218,7 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
     NOISE_CHECK_LAUNCH("noise_attn_core_fwd/mfma");
     return 0;
   }
-  const size_t smem = (size_t)2 * n * dk * sizeof(float);
-  NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_fwd: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
+  const size_t smem = (size_t)2 * attn_chunk_rows_host(n, dk) * ((dk + 3) / 4 * 4) * sizeof(float);
   NOISE_ALLOW_LDS(attn_core_fwd_kernel, smem);
   hipLaunchKernelGGL(attn_core_fwd_kernel, dim3((unsigned)(ntok / n) * heads), dim3(256), smem, (hipStream_t)stream, qkv, o,
                      ml, keep, seed, p_drop, d);
@@ -1171,8 +1254,8 @@ NOISE_EXPORT int noise_attn_core_bwd(const float* qkv, const float* d_o, const f
     NOISE_CHECK_LAUNCH("noise_attn_core_bwd/wave");
     return 0;
   }
-  const size_t smem = (size_t)(4 * n * dk + 3 * n) * sizeof(float);
-  NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_bwd: n=%d tokens per clip exceed the LDS limit", n);
+  const size_t smem = ((size_t)2 * attn_chunk_rows_host(n, dk) * ((dk + 3) / 4 * 4) + (size_t)3 * n) * sizeof(float);
+  NOISE_REQUIRE(smem <= 150 * 1024, "noise_attn_core_bwd: n=%d tokens per clip exceed the LDS limit (3 floats per token)", n);
   NOISE_ALLOW_LDS(attn_core_bwd_kernel, smem);
   hipLaunchKernelGGL(attn_core_bwd_kernel, dim3((unsigned)(ntok / n) * heads), dim3(256), smem, (hipStream_t)stream, qkv,
                      d_o, ml, keep, seed, p_drop, d_qkv, d);
