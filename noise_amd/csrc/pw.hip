@@ -282,8 +282,21 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(LazyGrad G, LazySrc A, La
 // (dy with the lazy BatchNorm backward applied, a with the lazy activation applied); each wave owns 16 of them.
 // LDS of one workgroup (floats) and the number of workgroups a CU can hold by that measure (at most 3-4): the register
 // budget is pinned to the same occupancy, otherwise the scheduler hoists every staged load and halves it.
+#ifdef PW_STAMPS
+__device__ unsigned long long g_pw_stamps[16];
+#define PW_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_pw_stamps[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define PW_T(i)
+#endif
+#ifndef PW_BWD_PF_MAX
+#define PW_BWD_PF_MAX 40
+#endif
+// Row pitch (floats) of a staged tile with `tiles` 16-channel tiles: 16-byte aligned rows, 4 banks apart.  (A pitch
+// congruent to 16 modulo 32 makes the weight-gradient operand reads conflict-free but the 128-bit row reads of the
+// input-gradient pass 8-way conflicted: measured 25 % slower on the 96 -> 32 layers.)
+constexpr int pw_bwd_pitch(int tiles) { return tiles * 16 + 4; }
 constexpr int pw_bwd_lds_floats(int KC, int MTI) {
-  return MTI * KC * 256 + WG_TILE * (KC * 16 + 4) + WG_TILE * (MTI * 16 + 4) + 5 * MTI * 16;
+  return MTI * KC * 256 + WG_TILE * pw_bwd_pitch(KC) + WG_TILE * pw_bwd_pitch(MTI) + 5 * MTI * 16;
 }
 constexpr int pw_bwd_min_blocks(int KC, int MTI) {
   const int b = 160 * 1024 / (pw_bwd_lds_floats(KC, MTI) * 4);
@@ -293,6 +306,17 @@ constexpr int pw_bwd_min_blocks(int KC, int MTI) {
 
 // rows of the 64-pixel tile a thread stages when a row has `tiles` 16-channel tiles (see the staging map below)
 constexpr int pw_bwd_passes(int tiles) { return (WG_TILE + 256 / (tiles * 4) - 1) / (256 / (tiles * 4)); }
+
+// PF: the next tile's global loads are requested while the current tile is multiplied and stay in registers until it
+// is staged, so the memory round trip of a tile hides behind MFMAs instead of relying on other resident workgroups.
+// Used where a CU holds at most two workgroups anyway (wide layers: LDS or the register cap), which leaves 256
+// registers per lane; the narrower layers run three or four workgroups per CU and spill with the extra live
+// registers, and with 96 input channels (6 tiles) the prefetch and the epilogue operands do not fit together
+// (measured 0.25 -> 0.33 ms on the 96 -> 24 layer with either of them spilled or split into rounds).
+constexpr bool pw_bwd_prefetch(int KC, int MTI, bool has_b) {
+  return pw_bwd_min_blocks(KC, MTI) <= 2 && MTI != 6 &&
+         2 * pw_bwd_passes(KC) + (has_b ? 2 : 1) * pw_bwd_passes(MTI) <= PW_BWD_PF_MAX;
+}
 
 // RY (expanding layers with at most 16 input channels, BatchNorm behind the layer; with more input channels the extra
 // MFMAs and barrier cost more than the read they save): the raw layer output y that the lazy
@@ -305,10 +329,13 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
                                                      float* __restrict__ g_in, BwdEpilogue E, float* __restrict__ dw_slab,
                                                      long npix, int N, int K) {
   extern __shared__ float lds[];
+#ifdef PW_STAMPS
+  unsigned long long last_ = clock64();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, q = lane >> 4;       // dgrad view: pixel lane / k-quarter;  wgrad view: i = p, kq = q
   constexpr int NP = KC * 16, KP = MTI * 16;
-  constexpr int pn = NP + 4, pk = KP + 4;
+  constexpr int pn = pw_bwd_pitch(KC), pk = pw_bwd_pitch(MTI);
   float* wfrag = lds;                            // [MTI][KC][64][4]
   float* dys = wfrag + MTI * KC * 256;           // [64][pn]
   float* as = dys + WG_TILE * pn;                // [64][pk]
@@ -402,35 +429,46 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
   const size_t gmul = E.g_other ? 1 : 0;
   const long ntiles = (npix + WG_TILE - 1) / WG_TILE;
   const long iters = (ntiles + gridDim.x - 1) / gridDim.x;
+  constexpr bool PF = pw_bwd_prefetch(KC, MTI, HAS_B);
+  constexpr bool ONE_ROUND = PF || 2 * PASS_N + (HAS_B ? 2 : 1) * PASS_K <= 12;
+  // input-channel tiles per epilogue round
+  constexpr int MC = MTI <= 6 ? MTI : (MTI % 6 == 0 ? 6 : 4);
+  float4 rz[PASS_N], ry[PASS_N], ra[PASS_K], rb[HAS_B ? PASS_K : 1];   // a thread's share of one staged tile
+  const int cnc1 = on ? cn : 0, ckc1 = ok ? ck : 0;
+  const int rnc1 = rn < RN ? rn : 0, rkc1 = rk < RK ? rk : 0;
+  auto issue_tile = [&](long tile_) {
+    const long p0 = tile_ * WG_TILE;
+#pragma unroll
+    for (int u = 0; u < PASS_N; ++u) {
+      long pix = p0 + rnc1 + u * RN;
+      pix = pix < npix ? pix : npix - 1;
+      const size_t off = (size_t)pix * N + cnc1;
+      rz[u] = ld4(G.dz + off);
+      ry[u] = (G.coef3 && !RY) ? ld4(G.y + off) : f4(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < PASS_K; ++u) {
+      long pix = p0 + rkc1 + u * RK;
+      pix = pix < npix ? pix : npix - 1;
+      const size_t off = (size_t)pix * K + ckc1;
+      ra[u] = ld4(A.y + off);
+      if (HAS_B) rb[u] = ld4(Bs.y + off);
+    }
+  };
+  if (PF) issue_tile(blockIdx.x);
+  PW_T(0);
   for (long it = 0; it < iters; ++it) {
     const long tile = (long)blockIdx.x + it * gridDim.x;
     const long pix0 = tile * WG_TILE;
     const long left = tile < ntiles ? npix - pix0 : 0;   // valid rows of this tile
     __syncthreads();
+    PW_T(1);
     // Every load is issued from a clamped (always valid) address, then transformed and stored.  When a thread's share
     // of the tile is small enough to sit in registers (ONE_ROUND) all of it is requested before the first use, so a
-    // tile costs one memory round trip; otherwise in batches of up to 4 rows.
-    constexpr bool ONE_ROUND = 2 * PASS_N + (HAS_B ? 2 : 1) * PASS_K <= 12;
+    // tile costs one memory round trip; otherwise in batches of up to 4 rows.  With PF the registers were filled
+    // while the previous tile was being multiplied (the request for the next tile follows the barrier below).
     if (ONE_ROUND) {
-      float4 rz[PASS_N], ry[PASS_N], ra[PASS_K], rb[HAS_B ? PASS_K : 1];
-      const int cnc = on ? cn : 0, ckc = ok ? ck : 0;
-      const int rnc = rn < RN ? rn : 0, rkc = rk < RK ? rk : 0;
-#pragma unroll
-      for (int u = 0; u < PASS_N; ++u) {
-        long pix = pix0 + rnc + u * RN;
-        pix = pix < npix ? pix : npix - 1;
-        const size_t off = (size_t)pix * N + cnc;
-        rz[u] = ld4(G.dz + off);
-        ry[u] = (G.coef3 && !RY) ? ld4(G.y + off) : f4(0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < PASS_K; ++u) {
-        long pix = pix0 + rkc + u * RK;
-        pix = pix < npix ? pix : npix - 1;
-        const size_t off = (size_t)pix * K + ckc;
-        ra[u] = ld4(A.y + off);
-        if (HAS_B) rb[u] = ld4(Bs.y + off);
-      }
+      if (!PF) issue_tile(tile);
       if (rn < RN) {
 #pragma unroll
         for (int u = 0; u < PASS_N; ++u) {
@@ -517,7 +555,9 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
       }
     }
     }
+    PW_T(2);
     __syncthreads();
+    PW_T(3);
     float4 in[KC];   // dy of this wave's 16 pixels: lane (p, q) holds channels 16jj + 4q .. + 3 of pixel p
 #pragma unroll
     for (int jj = 0; jj < KC; ++jj) in[jj] = ld4(dys + (16 * wave + p) * pn + 16 * jj + 4 * q);
@@ -553,52 +593,66 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
       const long pix = pix0 + 16 * wave + p;
       const bool valid = tile < ntiles && pix < npix;
       const size_t prow = (size_t)(pix < npix ? pix : npix - 1) * K;
-      // what the epilogue needs from memory is requested before the MFMA chains (clamped, always valid addresses)
-      // when the registers allow it (few input-channel tiles), otherwise tile by tile
-      constexpr bool PRE = MTI <= 6;
-      float4 yr[PRE ? MTI : 1], go[PRE ? MTI : 1];
-      if (PRE) {
+      // What the epilogue needs from memory is requested before the MFMA chains, from clamped (always valid)
+      // addresses with no branch around the loads: all input-channel tiles at once when the registers allow it,
+      // otherwise MC of them at a time (a wide layer then pays MTI / MC memory round trips per tile, not MTI).
+      // Memory operations complete in order: the next tile (PF) is requested AFTER the last loads this tile's
+      // epilogue waits for, so that wait does not include it, and it stays in flight through the MFMA chains.
 #pragma unroll
-        for (int m = 0; m < MTI; ++m) {
-          const int ci = 16 * m + 4 * q, cic = ci < K ? ci : 0;
-          yr[m] = ld4(A.y + prow + cic);
-          go[m] = ld4(gop + (prow + cic) * gmul);
+      for (int m0 = 0; m0 < MTI; m0 += MC) {
+        float4 yr[MC], go[MC];
+#pragma unroll
+        for (int u = 0; u < MC; ++u) {
+          const int ci = 16 * (m0 + u) + 4 * q, cic = (m0 + u < MTI && ci < K) ? ci : 0;
+#ifdef PW_DBG_NOLOAD
+          yr[u] = f4(1.f); go[u] = f4(0.f);
+#else
+          yr[u] = ld4(A.y + prow + cic);
+          go[u] = ld4(gop + (prow + cic) * gmul);
+#endif
         }
-      }
+        if (PF && m0 + MC >= MTI) issue_tile(tile + gridDim.x);
 #pragma unroll
-      for (int m = 0; m < MTI; ++m) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < MC; ++u) {
+          const int m = m0 + u;
+          if (m >= MTI) continue;
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jj = 0; jj < KC; ++jj) {
-          const float4 wa = ld4(wfrag + ((m * KC + jj) * 64 + lane) * 4);
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, o, 0, 0, 0);
-        }
-        const int ci = 16 * m + 4 * q;
-        if (valid && ci < K) {
-          const size_t off = prow + ci;
-          float4 g = make_float4(o[0], o[1], o[2], o[3]);
-          if (PRE) g = g + go[m];
-          else if (E.g_other) g = g + ld4(E.g_other + off);
-          if (E.coef) {
-            const float4 yraw = PRE ? yr[m] : ld4(A.y + off);
-            if (E.relu6) {
-              const float4 v = fma4(yraw, ld4(ecf + ci), ld4(ecf + KP + ci));
-              g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
-              g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
-              g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
-              g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
-            }
-            const float4 xh = sub4(sub4(yraw, ld4(ecf + 2 * KP + ci)), ld4(ecf + 4 * KP + ci)) * ld4(ecf + 3 * KP + ci);
-            s1[m] = s1[m] + g;
-            s2[m] = fma4(g, xh, s2[m]);
+          for (int jj = 0; jj < KC; ++jj) {
+            const float4 wa = ld4(wfrag + ((m * KC + jj) * 64 + lane) * 4);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, o, 0, 0, 0);
           }
-          st4(g_in + off, g);
+          const int ci = 16 * m + 4 * q;
+          if (valid && ci < K) {
+            const size_t off = prow + ci;
+            float4 g = make_float4(o[0], o[1], o[2], o[3]) + go[u];
+            if (E.coef) {
+              const float4 yraw = yr[u];
+              if (E.relu6) {
+                const float4 v = fma4(yraw, ld4(ecf + ci), ld4(ecf + KP + ci));
+                g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
+                g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
+                g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
+                g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
+              }
+              const float4 xh = sub4(sub4(yraw, ld4(ecf + 2 * KP + ci)), ld4(ecf + 4 * KP + ci)) * ld4(ecf + 3 * KP + ci);
+              s1[m] = s1[m] + g;
+              s2[m] = fma4(g, xh, s2[m]);
+            }
+#ifdef PW_DBG_NOSTORE
+            if (g.x == 123.456f) st4(g_in + off, g);
+#else
+            st4(g_in + off, g);
+#endif
+          }
         }
       }
     }
+    if (PF && g_in == nullptr) issue_tile(tile + gridDim.x);
+    PW_T(4);
     if (RY) __syncthreads();   // every wave has put its finished dy rows back
     // ---- wgrad: 16 k-steps of 4 pixels over this wave's tiles
 #pragma unroll 2
@@ -608,6 +662,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
       for (int j = 0; j < TPW; ++j)
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
     }
+    PW_T(5);
   }
 
   // ---- producer BN sums: reduce over the 16 pixel lanes, then over the waves
@@ -658,6 +713,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
   }
   __syncthreads();
   for (int j = tid; j < N * K; j += 256) dw_slab[(size_t)blockIdx.x * N * K + j] = lds[j];
+  PW_T(6);
 }
 
 __global__ __launch_bounds__(256) void pw_slab_reduce_kernel(const float* __restrict__ slab, int nrows, int ncols,
@@ -772,6 +828,16 @@ NOISE_EXPORT int noise_pw_wgrad(const float* dz, const float* y_out, const float
   return 0;
 }
 
+#ifdef PW_STAMPS
+NOISE_EXPORT int noise_debug_pw_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pw_stamps), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pw_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
+
 // Upper bound of workgroups (= slab rows) noise_pw_bwd uses for a Cout x Cin layer: enough to keep several
 // workgroups per CU in flight, while the dW slab stays below 16 MiB.
 NOISE_EXPORT int noise_pw_bwd_max_rows(int Cout, int Cin) {
@@ -804,7 +870,7 @@ NOISE_EXPORT int noise_pw_bwd(const float* dz, const float* y_out, const float* 
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   BwdEpilogue E{g_other, epi_coef, epi_relu6, epi_coef ? stats_slab : nullptr};
   int grid = noise_grid(npix, WG_TILE, noise_pw_bwd_max_rows(Cout, Cin));
-  size_t smem = (size_t)(MTI * KC * 256 + WG_TILE * (KC * 16 + 4) + WG_TILE * (MTI * 16 + 4) + 5 * MTI * 16) * sizeof(float);
+  size_t smem = (size_t)pw_bwd_lds_floats(KC, MTI) * sizeof(float);
   if ((size_t)Cout * Cin * sizeof(float) > smem) smem = (size_t)Cout * Cin * sizeof(float);
   NOISE_REQUIRE(smem <= 160 * 1024, "noise_pw_bwd: %dx%d layer needs %zu bytes of LDS", Cout, Cin, smem);
   hipStream_t st = (hipStream_t)stream;
