@@ -21,12 +21,16 @@ struct Attn16Dims {
 };
 
 __global__ __launch_bounds__(512) void attn_core_f16_kernel(const float* __restrict__ qkv, float* __restrict__ o, Attn16Dims d,
-                                                            int nsplit) {
+                                                            int nsplit, int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* ks = reinterpret_cast<_Float16*>(lds_raw);   // [n32][16], rows >= n and columns >= d_k zero
   _Float16* vt = ks + (size_t)d.n32 * 16;                 // [16][vp], V transposed, zero padded
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
-  const int split = blockIdx.x % nsplit, bh = blockIdx.x / nsplit;
+  // the splits of a (clip, head) restage the same K/V and the heads of a clip share every 32-byte sector of its qkv
+  // rows: consecutive virtual indices run on one XCD, so those bytes come from HBM once, not once per L2
+  const int vblk = xcd_chunked_block();
+  if (vblk >= total) return;
+  const int split = vblk % nsplit, bh = vblk / nsplit;
   const int b = bh / d.heads, h = bh % d.heads;
   const long base = (long)b * n;
   const int nthr = blockDim.x, nw = nthr >> 6;
@@ -125,8 +129,9 @@ NOISE_EXPORT int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, 
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
   NOISE_ALLOW_LDS(attn_core_f16_kernel, smem);
-  hipLaunchKernelGGL(attn_core_f16_kernel, dim3((unsigned)(bh * nsplit)), dim3(threads), smem, (hipStream_t)stream, qkv, o, d,
-                     nsplit);
+  const int total = (int)(bh * nsplit);
+  hipLaunchKernelGGL(attn_core_f16_kernel, dim3((unsigned)noise_pad8(total)), dim3(threads), smem, (hipStream_t)stream, qkv, o, d,
+                     nsplit, total);
   NOISE_CHECK_LAUNCH("noise_attn_core_fwd_f16");
   return 0;
 }
