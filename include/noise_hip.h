@@ -66,10 +66,10 @@ int noise_istft_bwd_sym(const float* d_wave, const float* wave_out, const float*
  * (320 = 2*16*10 and 512 = 2*16*16); results agree with the dense entry points to fp32 rounding. */
 int noise_fft_supported(int n_fft);
 int noise_stft_fwd_fft(const float* wave, const float* window, const float* tw1, const float* tw2, float* logmag,
-                       float* phase, float* absmax, int B, int L, int n_fft, int hop, void* stream);
+                       float* phase, float* absmax, int B, int L, int n_fft, int hop, int fast_math, void* stream);
 int noise_istft_fwd_fft(const float* logmag, const float* phase, const float* syn_window, const float* tw1, const float* tw2,
                         const float* window_sum, const float* vad_logit, float* wave_out, int B, int T, int n_fft, int hop,
-                        void* stream);
+                        int fast_math, void* stream);
 int noise_istft_bwd_fft(const float* d_wave, const float* wave_out, const float* logmag, const float* phase,
                         const float* syn_window, const float* tw1, const float* tw2, const float* window_sum,
                         float* d_logmag, int accumulate, int B, int T, int n_fft, int hop, void* stream);

@@ -17,8 +17,40 @@
 
 namespace {
 
+// Cheaper transcendental functions for the bf16 inference pipeline (absolute error about 1e-6 in the sine / cosine and
+// 2e-6 rad in the angle, far below that path's bf16 rounding); the fp32 paths keep the library functions.
+__device__ __forceinline__ float fast_atan2(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mn * __frcp_rn(fmaxf(mx, 1e-37f));
+  const float s = a * a;
+  // minimax odd polynomial of atan on [0, 1], degree 13
+  float r = -0.0117212f;
+  r = fmaf(r, s, 0.05265332f);
+  r = fmaf(r, s, -0.11643287f);
+  r = fmaf(r, s, 0.19354346f);
+  r = fmaf(r, s, -0.33262347f);
+  r = fmaf(r, s, 0.99997726f);
+  r = r * a;
+  r = ay > ax ? 1.57079637f - r : r;
+  r = x < 0.f ? 3.14159274f - r : r;
+  return copysignf(r, y);
+}
+__device__ __forceinline__ void fast_sincos(float a, float* sn, float* cs) {
+  *sn = __sinf(a);
+  *cs = __cosf(a);
+}
+
+#ifdef FFT_STAMPS
+__device__ unsigned long long g_fft_stamps[8];
+#define FFT_T(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_fft_stamps[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define FFT_T(i)
+#endif
+
 struct FftDims {
   int B, L, T, hop, F, Lout, accum;
+  int ntiles;   // frame tiles per clip; the grid is B * ntiles workgroups, padded to a multiple of 8
 };
 
 // Tables (device, caller-provided): win [N] window; tw1 [N2] = e^{-2 pi i j / N2}; tw2 [N2 + 1] = e^{-2 pi i k / N}.
@@ -33,7 +65,7 @@ struct FftLds {
 // MODE 0: forward -> log-magnitude, phase, per-clip max |log-magnitude|.
 // MODE 1: adjoint of the iSTFT: sig = dL/d(wave_out), masked where the output clamp was active and scaled by window_sum;
 //         writes dL/d(log-magnitude).
-template <int N2, int R1, int R2, int FR, int MODE>
+template <int N2, int R1, int R2, int FR, int MODE, bool FAST>
 __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restrict__ sig, const float* __restrict__ win,
                                                            const c32* __restrict__ tw1g, const c32* __restrict__ tw2g,
                                                            float* __restrict__ out0, float* __restrict__ out1,
@@ -49,30 +81,74 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
   float* wn = reinterpret_cast<float*>(tw2 + N2 + 1);       // [N]
   float* xs = wn + N;                                       // [(FR-1) hop + N]
   const int tid = threadIdx.x;
-  const int b = blockIdx.y, t0 = blockIdx.x * FR;
+#ifdef FFT_STAMPS
+  unsigned long long last_ = clock64();
+#endif
+  // Consecutive frame tiles of a clip write (forward) or read (adjoint) neighbouring runs of the same [F][T] rows, and
+  // with an odd T the runs share 128-byte lines: placed on one XCD they meet in one L2 (the writes merge into full
+  // lines, the reads fetch a line once) instead of producing partial-line traffic from eight L2s.
+  const int vblk = xcd_chunked_block();
+  if (vblk >= d.B * d.ntiles) return;
+  const int b = vblk / d.ntiles, t0 = (vblk - b * d.ntiles) * FR;
   const int hop = d.hop, half = N2;
   const int nS = (FR - 1) * hop + N;
-  for (int i = tid; i < N2; i += NT) tw1[i] = tw1g[i];
-  for (int i = tid; i <= N2; i += NT) tw2[i] = tw2g[i];
-  for (int i = tid; i < N; i += NT) wn[i] = win[i];
-  // ---- stage the samples of this tile (index in the padded signal = t0*hop + i)
-  for (int i = tid; i < nS; i += NT) {
-    int s = t0 * hop + i - half;
-    float v;
+  // ---- prologue: every global load (tables and this tile's samples; index in the padded signal = t0*hop + i) is
+  // requested before the first LDS store, from clamped addresses, so the workgroup pays one memory round trip
+  // instead of one per staging loop
+  constexpr int XPT = N / 16;                    // samples per thread at the largest hop (nS <= FR*N = XPT*NT)
+  constexpr int TWN = (N2 + NT) / NT, WNN = (N + NT - 1) / NT;
+  float xv[XPT], xw[MODE == 1 ? XPT : 1], xe[MODE == 1 ? XPT : 1];
+  c32 t1r[TWN], t2r[TWN];
+  float wr[WNN];
+#pragma unroll
+  for (int u = 0; u < XPT; ++u) {
+    const int i = tid + u * NT;
+    int s = t0 * hop + (i < nS ? i : 0) - half;
     if (MODE == 0) {
       if (s < 0) s = -s;
       if (s >= d.L) s = 2 * (d.L - 1) - s;
       s = min(max(s, 0), d.L - 1);      // only reached by frames past T (never stored)
-      v = sig[(size_t)b * d.L + s];
+      xv[u] = sig[(size_t)b * d.L + s];
     } else {
       const bool in = s >= 0 && s < d.Lout;
       const size_t o = (size_t)b * d.Lout + (in ? s : 0);
-      const float w = wave_out[o], g = sig[o], e = wsum[(in ? s : 0) + half];
-      v = (in && w > -1.f && w < 1.f) ? g * e : 0.f;
+      xw[u] = wave_out[o];
+      xv[u] = sig[o];
+      xe[u] = wsum[(in ? s : 0) + half];
     }
-    xs[i] = v;
   }
+#pragma unroll
+  for (int u = 0; u < TWN; ++u) {
+    const int k = tid + u * NT;
+    t1r[u] = tw1g[k < N2 ? k : N2 - 1];
+    t2r[u] = tw2g[k <= N2 ? k : N2];
+  }
+#pragma unroll
+  for (int u = 0; u < WNN; ++u) wr[u] = win[min(tid + u * NT, N - 1)];
+#pragma unroll
+  for (int u = 0; u < TWN; ++u) {
+    const int k = tid + u * NT;
+    if (k < N2) tw1[k] = t1r[u];
+    if (k <= N2) tw2[k] = t2r[u];
+  }
+#pragma unroll
+  for (int u = 0; u < WNN; ++u)
+    if (tid + u * NT < N) wn[tid + u * NT] = wr[u];
+#pragma unroll
+  for (int u = 0; u < XPT; ++u) {
+    const int i = tid + u * NT;
+    if (i < nS) {
+      float v = xv[u];
+      if (MODE == 1) {
+        const int s = t0 * hop + i - half;
+        v = (s >= 0 && s < d.Lout && xw[u] > -1.f && xw[u] < 1.f) ? v * xe[u] : 0.f;
+      }
+      xs[i] = v;
+    }
+  }
+  FFT_T(0);
   __syncthreads();
+  FFT_T(1);
   const int fr = tid >> 4, j = tid & 15;
   c32* zrow = zbuf + fr * ZP;
   // ---- pass A
@@ -89,9 +165,13 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
 #pragma unroll
     for (int k2 = 1; k2 < R2; ++k2) zrow[j * R2 + k2] = cmul(v[k2], tw1[j * k2]);
   }
+  FFT_T(2);
   __syncthreads();
+  FFT_T(3);
   fft_pass_b<R1, R2>(zrow, j);
+  FFT_T(4);
   __syncthreads();
+  FFT_T(5);
   // ---- split step + epilogue: thread = (frame, bin group); X[k] = E + W^k O, X[N2-k] = conj(E - W^k O) with
   // E = (Z[k] + conj Z[N2-k])/2, O = (Z[k] - conj Z[N2-k])/(2i)
   const int f2 = tid % FR, kg = tid / FR;        // 16 bin groups
@@ -118,10 +198,15 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
       const c32 xv = side == 0 ? xa : xb;
       const size_t oidx = ((size_t)b * d.F + f) * d.T + tc;
       if (MODE == 0) {
-        const float lm = logf(fmaxf(sqrtf(xv.x * xv.x + xv.y * xv.y), 1e-3f));
+        const float lm = FAST ? 0.5f * __logf(fmaxf(xv.x * xv.x + xv.y * xv.y, 1e-6f))
+                              : logf(fmaxf(sqrtf(xv.x * xv.x + xv.y * xv.y), 1e-3f));
+#ifdef FFT_DBG_NOSTORE
+        if (tin && lm == 123.456f) {
+#else
         if (tin) {
+#endif
           out0[oidx] = lm;
-          if (out1 != nullptr) out1[oidx] = atan2f(xv.y, xv.x);
+          if (out1 != nullptr) out1[oidx] = FAST ? fast_atan2(xv.y, xv.x) : atan2f(xv.y, xv.x);
           amax = fmaxf(amax, fabsf(lm));
         }
       } else {
@@ -135,6 +220,7 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
       }
     }
   }
+  FFT_T(6);
   if (MODE == 0 && absmax_bits != nullptr) {
     amax = wave_reduce_max(amax);
     if ((tid & 63) == 0) atomicMax(absmax_bits + b, __float_as_uint(amax));
@@ -143,7 +229,7 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
 
 // Inverse: spectrum -> frames (complex N2-point inverse transform via conjugation) -> synthesis window -> overlap-add.
 // A workgroup owns FR frames = FR - (N/hop - 1) output hops.
-template <int N2, int R1, int R2, int FR>
+template <int N2, int R1, int R2, int FR, bool FAST>
 __global__ __launch_bounds__(16 * FR) void istft_fft_kernel(const float* __restrict__ logmag, const float* __restrict__ phase,
                                                             const float* __restrict__ win, const c32* __restrict__ tw1g,
                                                             const c32* __restrict__ tw2g, const float* __restrict__ wsum,
@@ -156,30 +242,68 @@ __global__ __launch_bounds__(16 * FR) void istft_fft_kernel(const float* __restr
   c32* tw2 = tw1 + N2;
   float* wn = reinterpret_cast<float*>(tw2 + N2 + 1);
   const int tid = threadIdx.x;
-  const int b = blockIdx.y, hop = d.hop;
+  const int vblk = xcd_chunked_block();      // see stft_fft_kernel: neighbouring tiles share cache lines of the spectra
+  if (vblk >= d.B * d.ntiles) return;
+  const int b = vblk / d.ntiles, hop = d.hop;
   const int R = N / hop;
   const int TFo = FR - (R - 1);
-  const int q0 = blockIdx.x * TFo;        // first output hop of this tile
+  const int q0 = (vblk - b * d.ntiles) * TFo;        // first output hop of this tile
   const int tstart = q0 - (R - 1);        // first frame of this tile
-  for (int i = tid; i < N2; i += NT) tw1[i] = tw1g[i];
-  for (int i = tid; i <= N2; i += NT) tw2[i] = tw2g[i];
-  for (int i = tid; i < N; i += NT) wn[i] = win[i];
-  __syncthreads();
+  // ---- prologue: the tables and this thread's share of the spectrum are all requested before the first LDS store
+  // (one memory round trip per workgroup)
+  constexpr int TWN = (N2 + NT) / NT, WNN = (N + NT - 1) / NT;
+  constexpr int KI = (N2 / 2 + 16) / 16;         // bin pairs (k, N2 - k) per thread: k = kg + 16 u <= N2/2
+  const int f2 = tid % FR, kg = tid / FR;
+  const int t = tstart + f2;
+  const bool tin = t >= 0 && t < d.T;
+  const int tc = t < 0 ? 0 : (t < d.T ? t : d.T - 1);
+  float la[KI], lb[KI], pa[KI], pb[KI];
+  c32 twk[KI];                                   // e^{-2 pi i k / N} of this thread's bins, straight from the table
+#pragma unroll
+  for (int u = 0; u < KI; ++u) {
+    const int k = min(kg + 16 * u, N2 / 2), kb = N2 - k;
+    const size_t oa = ((size_t)b * d.F + k) * d.T + tc, ob = ((size_t)b * d.F + kb) * d.T + tc;
+    la[u] = logmag[oa];
+    lb[u] = logmag[ob];
+    pa[u] = phase[oa];
+    pb[u] = phase[ob];
+    twk[u] = tw2g[k];
+  }
+  c32 t1r[TWN];
+  float wr[WNN];
+#pragma unroll
+  for (int u = 0; u < TWN; ++u) {
+    const int k = tid + u * NT;
+    t1r[u] = tw1g[k < N2 ? k : N2 - 1];
+  }
+#pragma unroll
+  for (int u = 0; u < WNN; ++u) wr[u] = win[min(tid + u * NT, N - 1)];
+#pragma unroll
+  for (int u = 0; u < TWN; ++u) {
+    const int k = tid + u * NT;
+    if (k < N2) tw1[k] = t1r[u];
+  }
+#pragma unroll
+  for (int u = 0; u < WNN; ++u)
+    if (tid + u * NT < N) wn[tid + u * NT] = wr[u];
   // ---- spectrum -> conj(Z): Z[k] = E + iO, Z[N2-k] = conj(E) + i conj(O) with E = (X[k] + conj X[N2-k])/2,
-  // O = (X[k] - conj X[N2-k]) conj(W^k)/2; the imaginary parts of the DC and Nyquist bins are not used
+  // O = (X[k] - conj X[N2-k]) conj(W^k)/2; the imaginary parts of the DC and Nyquist bins are not used.
   {
-    const int f2 = tid % FR, kg = tid / FR;
-    const int t = tstart + f2;
-    const bool tin = t >= 0 && t < d.T;
-    const int tc = t < 0 ? 0 : (t < d.T ? t : d.T - 1);
     c32* zr = zbuf + f2 * ZP;
-    for (int k = kg; k <= N2 / 2; k += 16) {
+#pragma unroll
+    for (int u = 0; u < KI; ++u) {
+      const int k = kg + 16 * u;
+      if (k > N2 / 2) continue;
       const int kb = N2 - k;
-      const size_t oa = ((size_t)b * d.F + k) * d.T + tc, ob = ((size_t)b * d.F + kb) * d.T + tc;
-      const float ma = expf(logmag[oa]), mb = expf(logmag[ob]);
+      const float ma = FAST ? __expf(la[u]) : expf(la[u]), mb = FAST ? __expf(lb[u]) : expf(lb[u]);
       float sa, ca, sb, cb;
-      sincosf(phase[oa], &sa, &ca);
-      sincosf(phase[ob], &sb, &cb);
+      if (FAST) {
+        fast_sincos(pa[u], &sa, &ca);
+        fast_sincos(pb[u], &sb, &cb);
+      } else {
+        sincosf(pa[u], &sa, &ca);
+        sincosf(pb[u], &sb, &cb);
+      }
       c32 xa = {ma * ca, ma * sa}, xb = {mb * cb, mb * sb};
       if (!tin) xa = xb = {0.f, 0.f};
       if (k == 0) {
@@ -187,7 +311,7 @@ __global__ __launch_bounds__(16 * FR) void istft_fft_kernel(const float* __restr
       } else {
         const c32 e = {0.5f * (xa.x + xb.x), 0.5f * (xa.y - xb.y)};
         const c32 df = {0.5f * (xa.x - xb.x), 0.5f * (xa.y + xb.y)};
-        const c32 o = cmul(df, cconj(tw2[k]));
+        const c32 o = cmul(df, cconj(twk[u]));
         // Z[k] = E + iO = (e.x - o.y, e.y + o.x);  Z[N2-k] = conj(E) + i conj(O) = (e.x + o.y, -e.y + o.x)
         zr[k] = {e.x - o.y, -(e.y + o.x)};
         zr[kb] = {e.x + o.y, -(-e.y + o.x)};
@@ -245,24 +369,31 @@ size_t inv_smem() {
   return FftLds<N2, FR>::zbytes + (size_t)(N2 + N2 + 1) * 8 + (size_t)(2 * N2) * 4;
 }
 
-constexpr int FWD_FR = 16, INV_FR = 32;
+#ifndef FWD_FR_320
+#define FWD_FR_320 32
+#endif
+#ifndef FWD_FR_512
+#define FWD_FR_512 16
+#endif
+constexpr int INV_FR = 32;   // frames per workgroup: 32 consecutive frames of one bin are one 128-byte line of [B][F][T]
 
-template <int MODE>
+template <int MODE, bool FAST>
 int launch_fwd(int n_fft, const float* sig, const float* win, const float* tw1, const float* tw2, float* out0, float* out1,
                unsigned* absmax, const float* wave_out, const float* wsum, const float* logmag, const float* phase,
                FftDims d, hipStream_t st) {
-  dim3 grid(noise_cdiv(d.T, FWD_FR), d.B);
-#define FWD_CASE(NN, RA, RB)                                                                                          \
+#define FWD_CASE(NN, RA, RB, FRAMES)                                                                                  \
   if (n_fft == NN) {                                                                                                  \
-    const size_t smem = fwd_smem<NN / 2, FWD_FR>(d.hop);                                                              \
-    auto kfn = stft_fft_kernel<NN / 2, RA, RB, FWD_FR, MODE>;                                                         \
+    d.ntiles = noise_cdiv(d.T, FRAMES);                                                                               \
+    const dim3 grid(noise_pad8((long)d.ntiles * d.B));                                                                \
+    const size_t smem = fwd_smem<NN / 2, FRAMES>(d.hop);                                                              \
+    auto kfn = stft_fft_kernel<NN / 2, RA, RB, FRAMES, MODE, FAST>;                                                   \
     NOISE_ALLOW_LDS(kfn, smem);                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(16 * FWD_FR), smem, st, sig, win, (const c32*)tw1, (const c32*)tw2, out0, out1, \
+    hipLaunchKernelGGL(kfn, grid, dim3(16 * FRAMES), smem, st, sig, win, (const c32*)tw1, (const c32*)tw2, out0, out1, \
                        absmax, wave_out, wsum, logmag, phase, d);                                                     \
     return 0;                                                                                                         \
   }
-  FWD_CASE(320, 16, 10)
-  FWD_CASE(512, 16, 16)
+  FWD_CASE(320, 16, 10, FWD_FR_320)
+  FWD_CASE(512, 16, 16, FWD_FR_512)
 #undef FWD_CASE
   return 1;
 }
@@ -276,46 +407,64 @@ int check_fft(const char* who, int B, int n_fft, int hop) {
 
 }  // namespace
 
+#ifdef FFT_STAMPS
+NOISE_EXPORT int noise_debug_fft_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[8] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_stamps), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_stamps), 8 * sizeof(unsigned long long));
+}
+#endif
+
 NOISE_EXPORT int noise_fft_supported(int n_fft) { return n_fft == 320 || n_fft == 512; }
 
+// fast_math != 0: hardware-rate log / angle (the bf16 inference pipeline); 0: library functions (fp32 parity).
 NOISE_EXPORT int noise_stft_fwd_fft(const float* wave, const float* window, const float* tw1, const float* tw2, float* logmag,
-                                    float* phase, float* absmax, int B, int L, int n_fft, int hop, void* stream) {
+                                    float* phase, float* absmax, int B, int L, int n_fft, int hop, int fast_math,
+                                    void* stream) {
   if (check_fft("noise_stft_fwd_fft", B, n_fft, hop)) return -1;
   NOISE_REQUIRE(wave && window && tw1 && tw2 && logmag, "noise_stft_fwd_fft: null pointer");
   NOISE_REQUIRE(L > n_fft / 2, "noise_stft_fwd_fft: L=%d too short for reflect padding of %d", L, n_fft / 2);
   hipStream_t st = (hipStream_t)stream;
-  FftDims d{B, L, L / hop + 1, hop, n_fft / 2 + 1, hop * (L / hop), 0};
+  FftDims d{B, L, L / hop + 1, hop, n_fft / 2 + 1, hop * (L / hop), 0, 0};
   if (absmax) {
     hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * B, st);
     NOISE_REQUIRE(e == hipSuccess, "noise_stft_fwd_fft: memset failed: %s", hipGetErrorString(e));
   }
-  launch_fwd<0>(n_fft, wave, window, tw1, tw2, logmag, phase, (unsigned*)absmax, nullptr, nullptr, nullptr, nullptr, d, st);
+  if (fast_math)
+    launch_fwd<0, true>(n_fft, wave, window, tw1, tw2, logmag, phase, (unsigned*)absmax, nullptr, nullptr, nullptr, nullptr, d, st);
+  else
+    launch_fwd<0, false>(n_fft, wave, window, tw1, tw2, logmag, phase, (unsigned*)absmax, nullptr, nullptr, nullptr, nullptr, d, st);
   NOISE_CHECK_LAUNCH("noise_stft_fwd_fft");
   return 0;
 }
 
 NOISE_EXPORT int noise_istft_fwd_fft(const float* logmag, const float* phase, const float* syn_window, const float* tw1,
                                      const float* tw2, const float* window_sum, const float* vad_logit, float* wave_out, int B,
-                                     int T, int n_fft, int hop, void* stream) {
+                                     int T, int n_fft, int hop, int fast_math, void* stream) {
   if (check_fft("noise_istft_fwd_fft", B, n_fft, hop)) return -1;
   NOISE_REQUIRE(logmag && phase && syn_window && tw1 && tw2 && window_sum && wave_out, "noise_istft_fwd_fft: null pointer");
   NOISE_REQUIRE(T > 1, "noise_istft_fwd_fft: need at least 2 frames");
   const int R = n_fft / hop;
   NOISE_REQUIRE(R < INV_FR, "noise_istft_fwd_fft: n_fft/hop=%d too large", R);
   hipStream_t st = (hipStream_t)stream;
-  FftDims d{B, 0, T, hop, n_fft / 2 + 1, hop * (T - 1), 0};
+  FftDims d{B, 0, T, hop, n_fft / 2 + 1, hop * (T - 1), 0, 0};
   const int TFo = INV_FR - (R - 1), hops = T - 1 + R;
-  dim3 grid(noise_cdiv(hops, TFo), B);
-#define INV_CASE(NN, RA, RB)                                                                                            \
-  if (n_fft == NN) {                                                                                                    \
+  d.ntiles = noise_cdiv(hops, TFo);
+  dim3 grid(noise_pad8((long)d.ntiles * B));
+#define INV_CASE(NN, RA, RB, FAST)                                                                                      \
+  if (n_fft == NN && (fast_math != 0) == FAST) {                                                                        \
     const size_t smem = inv_smem<NN / 2, INV_FR>();                                                                     \
-    auto kfn = istft_fft_kernel<NN / 2, RA, RB, INV_FR>;                                                                \
+    auto kfn = istft_fft_kernel<NN / 2, RA, RB, INV_FR, FAST>;                                                          \
     NOISE_ALLOW_LDS(kfn, smem);                                                                                         \
     hipLaunchKernelGGL(kfn, grid, dim3(16 * INV_FR), smem, st, logmag, phase, syn_window, (const c32*)tw1, (const c32*)tw2, \
                        window_sum, vad_logit, wave_out, d);                                                             \
   }
-  INV_CASE(320, 16, 10)
-  INV_CASE(512, 16, 16)
+  INV_CASE(320, 16, 10, false)
+  INV_CASE(512, 16, 16, false)
+  INV_CASE(320, 16, 10, true)
+  INV_CASE(512, 16, 16, true)
 #undef INV_CASE
   NOISE_CHECK_LAUNCH("noise_istft_fwd_fft");
   return 0;
@@ -328,8 +477,8 @@ NOISE_EXPORT int noise_istft_bwd_fft(const float* d_wave, const float* wave_out,
   NOISE_REQUIRE(d_wave && wave_out && logmag && phase && syn_window && tw1 && tw2 && window_sum && d_logmag,
                 "noise_istft_bwd_fft: null pointer");
   NOISE_REQUIRE(T > 1, "noise_istft_bwd_fft: need at least 2 frames");
-  FftDims d{B, 0, T, hop, n_fft / 2 + 1, hop * (T - 1), accumulate};
-  launch_fwd<1>(n_fft, d_wave, syn_window, tw1, tw2, d_logmag, nullptr, nullptr, wave_out, window_sum, logmag, phase, d,
+  FftDims d{B, 0, T, hop, n_fft / 2 + 1, hop * (T - 1), accumulate, 0};
+  launch_fwd<1, false>(n_fft, d_wave, syn_window, tw1, tw2, d_logmag, nullptr, nullptr, wave_out, window_sum, logmag, phase, d,
                 (hipStream_t)stream);
   NOISE_CHECK_LAUNCH("noise_istft_bwd_fft");
   return 0;

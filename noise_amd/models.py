@@ -392,10 +392,11 @@ class VADSpectralV2(_LightningModule):
         """(B,1,1,L) -> enhanced (B,1,1,L') with L' = hop*(L//hop)   (train/models.py:745-756)."""
         _lib.require_cuda(waveforms)
         self._ensure_flat()
-        lm, ph, absmax = self.stft.forward(waveforms, return_absmax=True)
+        fast = self._fused_eval(self.training)      # the bf16 pipeline also takes the hardware-rate log / angle / sincos
+        lm, ph, absmax = self.stft.forward(waveforms, return_absmax=True, fast_math=fast)
         _, enh, vad = self._spectral(lm, absmax, self.training, seed=self._next_seed())
         B, _, H, W = lm.shape
-        return self.stft._inverse_raw(enh.view(B, 1, H, W), ph, vad)
+        return self.stft._inverse_raw(enh.view(B, 1, H, W), ph, vad, fast_math=fast)
 
     def graphed_forward(self, example):
         """Capture the eval forward for inputs shaped like `example` in a HIP graph and return `run(waveforms)`.

@@ -169,14 +169,16 @@ class STFT(torch.nn.Module):
     def num_frames(self, L):
         return L // self.hop_length + 1
 
-    def forward(self, waveform, return_absmax=False, reference_order=False, want_phase=True):
+    def forward(self, waveform, return_absmax=False, reference_order=False, want_phase=True, fast_math=False):
         """`reference_order=True` takes the general kernel, which accumulates every bin over the n_fft samples in
         the order of the reference's conv1d, even when the folded one is available.  The two agree to fp32
         rounding (the folded one is slightly closer to a float64 evaluation), but on bins near the 1e-3 magnitude
         floor that rounding is ~5e-5 of the log-magnitude, and the per-clip normaliser max|log-magnitude| of the
         denoiser (train/models.py:614-620) is usually attained there: the training step asks for the reference's
         order on the network input so that its normaliser, and with it every gradient, reproduces the
-        reference's to ~1e-6 instead of ~1e-3."""
+        reference's to ~1e-6 instead of ~1e-3.
+        `fast_math=True` (the bf16 inference pipeline; FFT kernels only) computes the log and the angle with
+        hardware-rate approximations (about 2e-6 absolute) instead of the library functions."""
         _lib.require_cuda(waveform, self.forward_basis)
         B = waveform.shape[0]
         L = waveform.shape[-1]
@@ -193,7 +195,7 @@ class STFT(torch.nn.Module):
         if fft is not None:
             _lib.call("noise_stft_fwd_fft", _lib.ptr(wave), _lib.ptr(fft[0]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
                       _lib.ptr(logmag), _lib.ptr(phase), _lib.ptr(absmax), B, L, self.n_fft, self.hop_length,
-                      _lib.stream(), nbytes=nbytes)
+                      int(bool(fast_math)), _lib.stream(), nbytes=nbytes)
         else:
             _lib.call("noise_stft_fwd_sym" if sym else "noise_stft_fwd", _lib.ptr(wave), _lib.ptr(basisF if sym else basisT),
                       _lib.ptr(logmag), _lib.ptr(phase), _lib.ptr(absmax), B, L, self.n_fft, self.hop_length, _lib.stream(),
@@ -202,7 +204,7 @@ class STFT(torch.nn.Module):
             return logmag, phase, absmax
         return logmag, phase
 
-    def _inverse_raw(self, log_magnitude, phase, vad_logit):
+    def _inverse_raw(self, log_magnitude, phase, vad_logit, fast_math=False):
         _lib.require_cuda(log_magnitude, phase, self.inverse_basis)
         B, _, F, T = log_magnitude.shape
         lm = log_magnitude.contiguous().float()
@@ -214,7 +216,7 @@ class STFT(torch.nn.Module):
         if fft is not None:
             _lib.call("noise_istft_fwd_fft", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(fft[1]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
                       _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft, self.hop_length,
-                      _lib.stream(), nbytes=8 * B * F * T + 4 * B * n_out)
+                      int(bool(fast_math)), _lib.stream(), nbytes=8 * B * F * T + 4 * B * n_out)
             return out
         _lib.call("noise_istft_fwd_sym" if self._bases()[0] else "noise_istft_fwd", _lib.ptr(lm), _lib.ptr(ph), _lib.ptr(self.inverse_basis),
                   _lib.ptr(self.window_sum), _lib.ptr(vad_logit), _lib.ptr(out), B, T, self.n_fft,
