@@ -86,6 +86,36 @@ __device__ __forceinline__ void tile_linear_mfma(const float* xt, int xpitch, co
     }
 }
 
+// og[(tok0 + t) * O + o] = sum_k xt[t][k] * Wl[o][k] straight from the accumulators (a lane holds 4 consecutive outputs
+// of one token = one 16-byte store; O is a multiple of 4), for this wave's tokens below ntok.
+template <int KSTEPS, int MT>
+__device__ __forceinline__ void tile_linear_mfma_global(const float* xt, int xpitch, const float* Wl, int wpitch, int O,
+                                                        float* __restrict__ og, long tok0, long ntok) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  f32x4 acc[MT];
+  int wrow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wrow[m] = (16 * m + p < O ? 16 * m + p : O - 1) * wpitch + q;
+  }
+  const float* xr = xt + (16 * wave + p) * xpitch + q;
+#pragma unroll 4
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const float b = xr[4 * ks];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[wrow[m] + 4 * ks], b, acc[m], 0, 0, 0);
+  }
+  const long tok = tok0 + 16 * wave + p;
+  if (tok < ntok) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int o = 16 * m + 4 * q;
+      if (o < O) st4(og + tok * O + o, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
+    }
+  }
+}
+
 // acc[n] += sum_t dy[t][16m + i] * x[t][16n + j] over the 64 tokens of a tile (n < NT): the weight-gradient tiles
 // (m, 0..NT-1) of dW = dy^T x.
 template <int NT>
@@ -162,8 +192,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
   const int O = 3 * d.hd;
   float* Wl = lds;                  // [O][WP]
   float* xs = Wl + O * WP;          // [TT][XS]
-  float* os = xs + TT * XS;         // [TT][O]
-  float* lw = os + TT * O;          // [2][D]
+  float* lw = xs + TT * XS;         // [2][D]
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
   for (int i = tid; i < O * D; i += 256) {
     const int o = i / D, k = i - o * D;
@@ -175,17 +204,30 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
     lw[i] = ln_w[i];
     lw[D + i] = ln_b[i];
   }
+  // the lazy transform of the bottleneck tensor: scale / shift of this thread's 4 columns (identity when absent) and
+  // the ReLU6 clamp as bounds, so the tile load has no branch around it
+  const int c4 = 4 * (tid & 15);
+  float4 xsc = f4(1.f), xsh = f4(0.f);
+  if (X.coef) {
+    xsc = ld4(X.coef + c4);
+    xsh = ld4(X.coef + D + c4);
+  }
+  const float xlo = X.relu6 ? 0.f : -INFINITY, xhi = X.relu6 ? 6.f : INFINITY;
   for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
     __syncthreads();
-    for (int i = tid; i < TT * D; i += 256) {
-      const int tt = i / D, c = i - tt * D;
-      float v = 0.f;
-      if (tok0 + tt < d.ntok) {
-        v = X.y[(tok0 + tt) * D + c];
-        if (X.coef) v = fmaf(v, X.coef[c], X.coef[D + c]);
-        if (X.relu6) v = relu6f(v);
+    {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {       // row tt = tid/16 + 16u, columns c4..c4+3: 16-byte pieces, clamped addresses
+        const long tok = tok0 + (tid >> 4) + 16 * u;
+        v[u] = ld4(X.y + (tok < d.ntok ? tok : d.ntok - 1) * D + c4);
       }
-      xs[tt * XS + c] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = (tid >> 4) + 16 * u;
+        const float4 a = clamp4(fma4(v[u], xsc, xsh), xlo, xhi);
+        st4(xs + tt * XS + c4, tok0 + tt < d.ntok ? a : f4(0.f));
+      }
     }
     __syncthreads();
     float* row = xs + t * XS;
@@ -194,10 +236,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
     if (valid) {
       if (part == 0) rstd0[tok0 + t] = rstd;
 #pragma unroll
-      for (int k = 0; k < D / 4; ++k) {
-        const int c = part * (D / 4) + k;
-        xhat0[(tok0 + t) * D + c] = row[c];
-      }
+      for (int k = 0; k < D / 16; ++k) st4(xhat0 + (tok0 + t) * D + part * (D / 4) + 4 * k, ld4(row + part * (D / 4) + 4 * k));
     }
 #pragma unroll
     for (int k = 0; k < D / 4; ++k) {
@@ -205,9 +244,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(LazySrc X, const floa
       row[c] = fmaf(row[c], lw[c], lw[D + c]);
     }
     __syncthreads();  // also orders the 4 lanes of a token (same wave) and the weight staging
-    tile_linear_mfma<D / 4, 12>(xs, XS, Wl, WP, O, os, O, nullptr, false, nullptr, 0);
-    __syncthreads();
-    tile_store(qkv, os, O, tok0, d.ntok, O);
+    tile_linear_mfma_global<D / 4, 12>(xs, XS, Wl, WP, O, qkv, tok0, d.ntok);
   }
 }
 
@@ -1158,10 +1195,11 @@ NOISE_EXPORT int noise_attn_pre_fwd(const float* x_y, const float* x_coef, int x
   NOISE_REQUIRE(x_y && ln_w && ln_b && wq && wk && wv && xhat0 && rstd0 && qkv, "noise_attn_pre_fwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   const int O = 3 * d.hd;
-  const size_t smem = (size_t)(O * WP + TT * XS + TT * O + 2 * D) * sizeof(float);
+  const size_t smem = (size_t)(O * WP + TT * XS + 2 * D) * sizeof(float);
   LazySrc X{x_y, x_coef, x_relu6};
   NOISE_ALLOW_LDS(attn_pre_fwd_kernel, smem);
-  hipLaunchKernelGGL(attn_pre_fwd_kernel, dim3(noise_grid(ntok, TT, ATTN_MAX_BLOCKS)), dim3(256), smem, (hipStream_t)stream, X, ln_w,
+  // no per-workgroup slab in the forward direction: two workgroups per CU (67 KB of LDS each)
+  hipLaunchKernelGGL(attn_pre_fwd_kernel, dim3(noise_grid(ntok, TT, 2 * ATTN_MAX_BLOCKS)), dim3(256), smem, (hipStream_t)stream, X, ln_w,
                      ln_b, wq, wk, wv, xhat0, rstd0, qkv, d);
   NOISE_CHECK_LAUNCH("noise_attn_pre_fwd");
   return 0;

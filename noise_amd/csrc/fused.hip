@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
     }
   };
 
-  int tile = blockIdx.x;
+  // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
+  int tile = xcd_chunked_block();
   if (tile < ntiles) prefetch(tile);
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
@@ -351,7 +352,7 @@ int launch_ir(const IrArgs& a0, hipStream_t st) {
   static int per_cu = 0;      // resident workgroups per CU of this instantiation (asked once)
   if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, smem) != hipSuccess || per_cu < 1)) per_cu = 1;
   const long cap = (long)noise_num_cus() * per_cu;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)noise_pad8(ntiles < cap ? ntiles : cap)), dim3(256), smem, st, a);
   return 0;
 }
 
@@ -440,7 +441,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       finside |= inside ? (1u << u) : 0u;
     }
   };
-  int tile = blockIdx.x;
+  // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
+  int tile = xcd_chunked_block();
   if (tile < ntiles) prefetch(tile);
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
@@ -633,7 +635,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       prea[u] = *reinterpret_cast<const bf16x8*>(a0b + (iy * a.Ws0 + ix) * 32 + c8);
     }
   };
-  int tile = blockIdx.x;
+  // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
+  int tile = xcd_chunked_block();
   if (tile < ntiles) prefetch(tile);
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
@@ -794,7 +797,7 @@ NOISE_EXPORT int noise_fused_head(const float* logmag, const float* absmax, cons
   static int per_cu = 0;
   if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_kernel, 256, 0) != hipSuccess || per_cu < 1)) per_cu = 1;
   const long cap = (long)noise_num_cus() * per_cu;
-  hipLaunchKernelGGL(head_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(head_kernel, dim3((unsigned)noise_pad8(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream, a);
   NOISE_CHECK_LAUNCH("noise_fused_head");
   return 0;
 }
@@ -829,7 +832,7 @@ NOISE_EXPORT int noise_fused_tail(const void* d2, const void* a1, int Hs1, int W
   static int per_cu = 0;
   if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tail_kernel, 256, 0) != hipSuccess || per_cu < 1)) per_cu = 1;
   const long cap = (long)noise_num_cus() * per_cu;
-  hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(tail_kernel, dim3((unsigned)noise_pad8(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream, a);
   NOISE_CHECK_LAUNCH("noise_fused_tail");
   return 0;
 }
