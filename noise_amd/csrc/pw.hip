@@ -313,6 +313,12 @@ constexpr int pw_bwd_passes(int tiles) { return (WG_TILE + 256 / (tiles * 4) - 1
 // registers per lane; the narrower layers run three or four workgroups per CU and spill with the extra live
 // registers, and with 96 input channels (6 tiles) the prefetch and the epilogue operands do not fit together
 // (measured 0.25 -> 0.33 ms on the 96 -> 24 layer with either of them spilled or split into rounds).
+// WGF: the weight-gradient MFMAs run between the request for the input-gradient epilogue's operands and their first
+// use.  Kept where the extra live registers fit (measured per instantiation: 72 -> 16 layer 0.61 -> 0.58 ms, 32 -> 16
+// layer 0.28 -> 0.26 ms); the instantiations that spill with it lose 10-30 %.
+constexpr bool pw_bwd_wgrad_first(int KC, int MTI, bool has_b) {
+  return !has_b && ((KC == 1 && (MTI == 2 || MTI == 5)) || (KC == 2 && (MTI == 3 || MTI == 6)));
+}
 constexpr bool pw_bwd_prefetch(int KC, int MTI, bool has_b) {
   return pw_bwd_min_blocks(KC, MTI) <= 2 && MTI != 6 &&
          2 * pw_bwd_passes(KC) + (has_b ? 2 : 1) * pw_bwd_passes(MTI) <= PW_BWD_PF_MAX;
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
   const long ntiles = (npix + WG_TILE - 1) / WG_TILE;
   const long iters = (ntiles + gridDim.x - 1) / gridDim.x;
   constexpr bool PF = pw_bwd_prefetch(KC, MTI, HAS_B);
+  constexpr bool WGF = pw_bwd_wgrad_first(KC, MTI, HAS_B);
   constexpr bool ONE_ROUND = PF || 2 * PASS_N + (HAS_B ? 2 : 1) * PASS_K <= 12;
   // input-channel tiles per epilogue round
   constexpr int MC = MTI <= 6 ? MTI : (MTI % 6 == 0 ? 6 : 4);
@@ -588,6 +595,18 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
         st4(dys + (16 * wave + p) * pn + co, in[jj]);
       }
     }
+    if (RY) __syncthreads();   // every wave has put its finished dy rows back
+    // ---- wgrad: 16 k-steps of 4 pixels over this wave's tiles.  It only reads the staged tiles, so it runs between
+    // the request for the input-gradient epilogue's operands and their first use: the MFMAs cover that round trip.
+    auto wgrad_pass = [&]() {
+#pragma unroll 2
+      for (int s = 0; s < 16; ++s) {
+        const int pp = 4 * s + q;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
+      }
+    };
     // ---- dgrad for this wave's 16 pixels
     if (g_in != nullptr) {
       const long pix = pix0 + 16 * wave + p;
@@ -612,6 +631,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
 #endif
         }
         if (PF && m0 + MC >= MTI) issue_tile(tile + gridDim.x);
+        if (WGF && m0 == 0) wgrad_pass();
 #pragma unroll
         for (int u = 0; u < MC; ++u) {
           const int m = m0 + u;
@@ -653,15 +673,7 @@ __global__ __launch_bounds__(256, pw_bwd_min_blocks(KC, MTI)) void pw_bwd_kernel
     }
     if (PF && g_in == nullptr) issue_tile(tile + gridDim.x);
     PW_T(4);
-    if (RY) __syncthreads();   // every wave has put its finished dy rows back
-    // ---- wgrad: 16 k-steps of 4 pixels over this wave's tiles
-#pragma unroll 2
-    for (int s = 0; s < 16; ++s) {
-      const int pp = 4 * s + q;
-#pragma unroll
-      for (int j = 0; j < TPW; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
-    }
+    if (!WGF || g_in == nullptr) wgrad_pass();
     PW_T(5);
   }
 
