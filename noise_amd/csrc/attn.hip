@@ -820,37 +820,42 @@ struct PostParams {
   const float *fc, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b, *vad_w, *vad_b;
 };
 
-__global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restrict__ o, const float* __restrict__ xhat0,
-                                                            const float* __restrict__ ln0_w, const float* __restrict__ ln0_b,
-                                                            PostParams P, float* __restrict__ xhat1, float* __restrict__ rstd1,
-                                                            float* __restrict__ hdn, float* __restrict__ xhat2,
-                                                            float* __restrict__ rstd2, float* __restrict__ x3,
-                                                            float* __restrict__ vad, AttnDims d) {
+// The forward of everything behind the attention core runs as two kernels so that each keeps few enough weights in
+// LDS for two or three workgroups per CU (one kernel with all three matrices and three token tiles needs 107 KB: one
+// workgroup per CU, every global load and barrier of the chain exposed).  tile_linear_mfma may write its result over
+// its residual operand: a lane reads the residual element it is about to overwrite, and a wave only touches the rows
+// of its own 16 tokens.
+
+// 16-byte store of a thread's 16 columns of token row `row` (LDS) to g[(tok) * D + ...]
+__device__ __forceinline__ void row_store16(float* g, long tok, const float* row, int part) {
+#pragma unroll
+  for (int k = 0; k < D / 16; ++k) st4(g + tok * D + part * (D / 4) + 4 * k, ld4(row + part * (D / 4) + 4 * k));
+}
+
+// C1: y1 = o Wfc^T + x1 (x1 = g0*xhat0 + b0) -> xhat1, rstd1
+__global__ __launch_bounds__(256) void attn_post_fc_kernel(const float* __restrict__ o, const float* __restrict__ xhat0,
+                                                           const float* __restrict__ ln0_w, const float* __restrict__ ln0_b,
+                                                           const float* __restrict__ fc, float* __restrict__ xhat1,
+                                                           float* __restrict__ rstd1, AttnDims d) {
   extern __shared__ float lds[];
   const int HD = d.hd;
   float* Wfc = lds;                 // [D][WP], columns >= HD zero
-  float* W1 = Wfc + D * WP;         // [D][WP]
-  float* W2 = W1 + D * WP;          // [D][WP]
-  float* vec = W2 + D * WP;         // ln0_w, ln0_b, ln1_w, ln1_b, b1, b2, ln2_w, ln2_b, vad_w  (9*D)
-  float* ta = vec + 9 * D;          // [TT][XS]
-  float* tb = ta + TT * XS;         // [TT][XS]
-  float* tc = tb + TT * XS;         // [TT][XS]
+  float* vec = Wfc + D * WP;        // ln0_w, ln0_b
+  float* ta = vec + 2 * D;          // [TT][XS]  o, columns >= HD zero
+  float* tb = ta + TT * XS;         // [TT][XS]  xhat0 -> x1 -> y1 -> xhat1
   const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
   for (int i = tid; i < D * D; i += 256) {
     const int oo = i / D, k = i - oo * D;
-    Wfc[oo * WP + k] = k < HD ? P.fc[oo * HD + k] : 0.f;
-    W1[oo * WP + k] = P.w1[i];
-    W2[oo * WP + k] = P.w2[i];
+    Wfc[oo * WP + k] = k < HD ? fc[oo * HD + k] : 0.f;
   }
   for (int i = tid; i < D; i += 256) {
-    vec[i] = ln0_w[i]; vec[D + i] = ln0_b[i]; vec[2 * D + i] = P.ln1_w[i]; vec[3 * D + i] = P.ln1_b[i];
-    vec[4 * D + i] = P.b1[i]; vec[5 * D + i] = P.b2[i]; vec[6 * D + i] = P.ln2_w[i]; vec[7 * D + i] = P.ln2_b[i];
-    vec[8 * D + i] = P.vad_w[i];
+    vec[i] = ln0_w[i];
+    vec[D + i] = ln0_b[i];
   }
   for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
     __syncthreads();
-    tile_load_padded(ta, XS, o, tok0, d.ntok, HD, D);   // ta = o, columns >= HD zero
-    tile_load(tb, XS, xhat0, tok0, d.ntok, D);    // tb = xhat0 -> x1
+    tile_load_padded(ta, XS, o, tok0, d.ntok, HD, D);
+    tile_load(tb, XS, xhat0, tok0, d.ntok, D);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < D / 4; ++k) {
@@ -858,48 +863,69 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(const float* __restr
       tb[t * XS + c] = fmaf(tb[t * XS + c], vec[c], vec[D + c]);
     }
     __syncthreads();
-    // tc = y1 = o Wfc^T + x1
-    tile_linear_mfma<D / 4, 4>(ta, XS, Wfc, WP, D, tc, XS, nullptr, false, tb, XS);
+    tile_linear_mfma<D / 4, 4>(ta, XS, Wfc, WP, D, tb, XS, nullptr, false, tb, XS);   // tb = y1 (in place over x1)
+    __syncthreads();
+    const float r1 = ln_row(tb + t * XS, part, 1e-6f);   // tb = xhat1
+    if (tok0 + t < d.ntok) {
+      if (part == 0) rstd1[tok0 + t] = r1;
+      row_store16(xhat1, tok0 + t, tb + t * XS, part);
+    }
+  }
+}
+
+// C2: x2 = g1*xhat1 + b1 -> hdn = relu(x2 W1^T + b1) -> y2 = hdn W2^T + b2 + x2 -> xhat2, rstd2, x3, VAD logit
+__global__ __launch_bounds__(256) void attn_post_ffn_kernel(const float* __restrict__ xhat1, PostParams P,
+                                                            float* __restrict__ hdn, float* __restrict__ xhat2,
+                                                            float* __restrict__ rstd2, float* __restrict__ x3,
+                                                            float* __restrict__ vad, AttnDims d) {
+  extern __shared__ float lds[];
+  float* W1 = lds;                  // [D][WP]
+  float* W2 = W1 + D * WP;          // [D][WP]
+  float* vec = W2 + D * WP;         // ln1_w, ln1_b, b1, b2, ln2_w, ln2_b, vad_w  (7*D)
+  float* ta = vec + 7 * D;          // [TT][XS]  hdn
+  float* tb = ta + TT * XS;         // [TT][XS]  xhat1 -> x2 -> y2 -> xhat2 -> x3
+  const int tid = threadIdx.x, t = tid >> 2, part = tid & 3;
+  for (int i = tid; i < D * D; i += 256) {
+    const int oo = i / D, k = i - oo * D;
+    W1[oo * WP + k] = P.w1[i];
+    W2[oo * WP + k] = P.w2[i];
+  }
+  for (int i = tid; i < D; i += 256) {
+    vec[i] = P.ln1_w[i]; vec[D + i] = P.ln1_b[i]; vec[2 * D + i] = P.b1[i]; vec[3 * D + i] = P.b2[i];
+    vec[4 * D + i] = P.ln2_w[i]; vec[5 * D + i] = P.ln2_b[i]; vec[6 * D + i] = P.vad_w[i];
+  }
+  for (long tok0 = (long)blockIdx.x * TT; tok0 < d.ntok; tok0 += (long)gridDim.x * TT) {
+    __syncthreads();
+    tile_load(tb, XS, xhat1, tok0, d.ntok, D);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const int c = part * (D / 4) + k;
+      tb[t * XS + c] = fmaf(tb[t * XS + c], vec[c], vec[D + c]);   // tb = x2
+    }
+    __syncthreads();
+    tile_linear_mfma<D / 4, 4>(tb, XS, W1, WP, D, ta, XS, vec + 2 * D, true, nullptr, 0);   // ta = hdn
+    __syncthreads();
+    tile_store(hdn, ta, XS, tok0, d.ntok, D);
+    tile_linear_mfma<D / 4, 4>(ta, XS, W2, WP, D, tb, XS, vec + 3 * D, false, tb, XS);      // tb = y2 (in place over x2)
     __syncthreads();
     const bool valid = tok0 + t < d.ntok;
-    float r1 = ln_row(tc + t * XS, part, 1e-6f);   // tc = xhat1
+    const float r2 = ln_row(tb + t * XS, part, 1e-6f);   // tb = xhat2
     if (valid) {
-      if (part == 0) rstd1[tok0 + t] = r1;
-#pragma unroll
-      for (int k = 0; k < D / 4; ++k) {
-        const int c = part * (D / 4) + k;
-        xhat1[(tok0 + t) * D + c] = tc[t * XS + c];
-      }
+      if (part == 0) rstd2[tok0 + t] = r2;
+      row_store16(xhat2, tok0 + t, tb + t * XS, part);
     }
 #pragma unroll
     for (int k = 0; k < D / 4; ++k) {
       const int c = part * (D / 4) + k;
-      tc[t * XS + c] = fmaf(tc[t * XS + c], vec[2 * D + c], vec[3 * D + c]);   // tc = x2
+      tb[t * XS + c] = fmaf(tb[t * XS + c], vec[4 * D + c], vec[5 * D + c]);   // tb = x3
     }
-    __syncthreads();
-    tile_linear_mfma<D / 4, 4>(tc, XS, W1, WP, D, ta, XS, vec + 4 * D, true, nullptr, 0);   // ta = hdn
-    __syncthreads();
-    tile_store(hdn, ta, XS, tok0, d.ntok, D);
-    tile_linear_mfma<D / 4, 4>(ta, XS, W2, WP, D, tb, XS, vec + 5 * D, false, tc, XS);      // tb = y2
-    __syncthreads();
-    float r2 = ln_row(tb + t * XS, part, 1e-6f);   // tb = xhat2
-    if (valid) {
-      if (part == 0) rstd2[tok0 + t] = r2;
-#pragma unroll
-      for (int k = 0; k < D / 4; ++k) {
-        const int c = part * (D / 4) + k;
-        const float xh = tb[t * XS + c];
-        xhat2[(tok0 + t) * D + c] = xh;
-        const float v = fmaf(xh, vec[6 * D + c], vec[7 * D + c]);
-        x3[(tok0 + t) * D + c] = v;
-        tb[t * XS + c] = v;
-      }
-    }
+    if (valid) row_store16(x3, tok0 + t, tb + t * XS, part);
     __syncthreads();
     // VAD head on the first token of each clip
     if (valid && part == 0 && (tok0 + t) % d.n == 0) {
       float acc = P.vad_b[0];
-      for (int c = 0; c < D; ++c) acc = fmaf(tb[t * XS + c], vec[8 * D + c], acc);
+      for (int c = 0; c < D; ++c) acc = fmaf(tb[t * XS + c], vec[6 * D + c], acc);
       vad[(tok0 + t) / d.n] = acc;
     }
   }
@@ -1313,10 +1339,15 @@ NOISE_EXPORT int noise_attn_post_fwd(const float* o, const float* xhat0, const f
                 "noise_attn_post_fwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
   PostParams P{fc, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b, vad_w, vad_b};
-  const size_t smem = (size_t)(3 * D * WP + 9 * D + 3 * TT * XS) * sizeof(float);
-  NOISE_ALLOW_LDS(attn_post_fwd_kernel, smem);
-  hipLaunchKernelGGL(attn_post_fwd_kernel, dim3(noise_grid(ntok, TT, ATTN_MAX_BLOCKS)), dim3(256), smem, (hipStream_t)stream, o, xhat0,
-                     ln0_w, ln0_b, P, xhat1, rstd1, hdn, xhat2, rstd2, x3, vad, d);
+  // no per-workgroup slab in the forward direction: the grids follow what a CU holds (3 and 2 workgroups)
+  const size_t sm1 = (size_t)(D * WP + 2 * D + 2 * TT * XS) * sizeof(float);
+  const size_t sm2 = (size_t)(2 * D * WP + 7 * D + 2 * TT * XS) * sizeof(float);
+  NOISE_ALLOW_LDS(attn_post_fc_kernel, sm1);
+  NOISE_ALLOW_LDS(attn_post_ffn_kernel, sm2);
+  hipLaunchKernelGGL(attn_post_fc_kernel, dim3(noise_grid(ntok, TT, 3 * ATTN_MAX_BLOCKS)), dim3(256), sm1, (hipStream_t)stream, o,
+                     xhat0, ln0_w, ln0_b, fc, xhat1, rstd1, d);
+  hipLaunchKernelGGL(attn_post_ffn_kernel, dim3(noise_grid(ntok, TT, 2 * ATTN_MAX_BLOCKS)), dim3(256), sm2, (hipStream_t)stream,
+                     xhat1, P, hdn, xhat2, rstd2, x3, vad, d);
   NOISE_CHECK_LAUNCH("noise_attn_post_fwd");
   return 0;
 }
