@@ -4,10 +4,11 @@
 // half-precision operands on the matrix cores, fp32 scores, online softmax, so the n x n scores are never stored.
 // K and V^T of one (clip, head) live in LDS; a wave owns 16 queries and walks the keys 32 at a time:
 //     S^T [key][query] = K Q^T          two v_mfma_f32_16x16x16_f16 (d_k <= 16 is the reduction index)
-//     running max / rescale / p = exp(s - m)
+//     running max / rescale (only when some query's maximum moved) / p = 2^(s - m), scores pre-scaled by log2(e)
 //     O^T [d][query] += V^T P^T         one v_mfma_f32_16x16x32_f16 whose 32-deep reduction index is laid out so that
 //                                       the lane's own 8 probabilities are its B fragment (no shuffles): slot j of
-//                                       lane group q is key 4q + j (j < 4) or 16 + 4q + (j - 4)
+//                                       lane group q is key 4q + j (j < 4) or 16 + 4q + (j - 4); row d_k of V^T is
+//                                       all ones, so output row d_k is the sum of the weights (the normaliser)
 #include "common.h"
 
 namespace {
@@ -17,7 +18,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 struct Attn16Dims {
   long ntok;
-  int n, heads, dk, hd, n32, vp;   // n32 = n rounded up to 32; vp = row pitch of V^T (halves)
+  int n, heads, dk, hd, n32, vp;   // n32 = n rounded up to the 64 keys of a step; vp = row pitch of V^T (halves)
 };
 
 __global__ __launch_bounds__(512) void attn_core_f16_kernel(const float* __restrict__ qkv, float* __restrict__ o, Attn16Dims d,
@@ -40,12 +41,13 @@ __global__ __launch_bounds__(512) void attn_core_f16_kernel(const float* __restr
     const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : dk - 1);
     const float kv = row[d.hd], vv = row[2 * d.hd];
     ks[i] = (_Float16)(in ? kv : 0.f);
-    vt[c * d.vp + j] = (_Float16)(in ? vv : 0.f);
+    // row d_k of V^T is all ones over the real keys: the P V product then carries sum_j p_j in output row d_k
+    vt[c * d.vp + j] = (_Float16)(in ? vv : ((c == dk && j < n) ? 1.f : 0.f));   // (d_k = 16 leaves no spare row)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
-  const float qscale = 1.f / sqrtf((float)dk);
-  const int ntile = (n + 15) >> 4, nblk = d.n32 >> 5;
+  const float qscale = 1.44269504f / sqrtf((float)dk);   // scores in units of log 2: p = 2^(s - m)
+  const int ntile = (n + 15) >> 4, nblk = d.n32 >> 6;
   for (int qt = split * nw + wave; qt < ntile; qt += nw * nsplit) {
     const int qi = qt * 16 + p;
     const bool valid = qi < n;
@@ -54,50 +56,67 @@ __global__ __launch_bounds__(512) void attn_core_f16_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) qb[r] = (_Float16)((4 * q + r < dk) ? qrow[4 * q + r] * qscale : 0.f);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
-    for (int kb = 0; kb < nblk; ++kb) {
-      const int key0 = 32 * kb;
-      const f16x4 ka0 = *reinterpret_cast<const f16x4*>(ks + (key0 + p) * 16 + 4 * q);
-      const f16x4 ka1 = *reinterpret_cast<const f16x4*>(ks + (key0 + 16 + p) * 16 + 4 * q);
-      const f16x4 va0 = *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 4 * q);
-      const f16x4 va1 = *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 16 + 4 * q);
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ka0, qb, zero, 0, 0, 0);
-      f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ka1, qb, zero, 0, 0, 0);
-      if (key0 + 32 > n) {      // only the last block holds keys past the clip
+    float m = -INFINITY, lsum = 0.f;      // lsum: the sum of the weights when d_k = 16 leaves no spare output row
+    for (int kb = 0; kb < nblk; ++kb) {      // 64 keys per step: two independent score / weight chains in flight
+      const int key0 = 64 * kb;
+      f16x4 ka[4], va[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (key0 + 4 * q + r >= n) s0[r] = -INFINITY;
-          if (key0 + 16 + 4 * q + r >= n) s1[r] = -INFINITY;
-        }
+      for (int g = 0; g < 4; ++g) {
+        ka[g] = *reinterpret_cast<const f16x4*>(ks + (key0 + 16 * g + p) * 16 + 4 * q);
+        va[g] = *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 16 * g + 4 * q);
       }
-      float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      f32x4 sv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sv[g] = __builtin_amdgcn_mfma_f32_16x16x16f16(ka[g], qb, zero, 0, 0, 0);
+      if (key0 + 64 > n) {      // only the last step holds keys past the clip
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + 16 * g + 4 * q + r >= n) sv[g][r] = -INFINITY;
+      }
+      float bm = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bm = fmaxf(bm, fmaxf(fmaxf(sv[g][0], sv[g][1]), fmaxf(sv[g][2], sv[g][3])));
       bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
       bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m, bm);          // finite: every block holds at least one real key
-      const float sc = __expf(m - mn);
-      float pr[8];
+      if (__any(bm > m)) {                    // the running maximum of some query moved: rescale what is accumulated
+        const float mn = fmaxf(m, bm);        // finite: every step holds at least one real key
+        const float sc = __builtin_amdgcn_exp2f(m - mn);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pr[r] = __expf(s0[r] - mn);
-        pr[4 + r] = __expf(s1[r] - mn);
+        for (int r = 0; r < 4; ++r) acc[r] *= sc;
+        lsum *= sc;
+        m = mn;
       }
-      l = l * sc + (((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] *= sc;
-      f16x8 pb, va;
+      for (int h2 = 0; h2 < 2; ++h2) {
+        f16x8 pb, vv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pb[r] = (_Float16)pr[r];
-        pb[4 + r] = (_Float16)pr[4 + r];
-        va[r] = va0[r];
-        va[4 + r] = va1[r];
+        for (int r = 0; r < 4; ++r) {
+          pb[r] = (_Float16)__builtin_amdgcn_exp2f(sv[2 * h2][r] - m);
+          pb[4 + r] = (_Float16)__builtin_amdgcn_exp2f(sv[2 * h2 + 1][r] - m);
+          vv[r] = va[2 * h2][r];
+          vv[4 + r] = va[2 * h2 + 1][r];
+        }
+        if (dk == 16) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) lsum += (float)pb[r];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(vv, pb, acc, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, acc, 0, 0, 0);
-      m = mn;
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    // output row d_k (lane group q = d_k / 4, register d_k % 4) holds the sum of this query's weights
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if ((dk & 3) == r) l = acc[r];
+    l = __shfl(l, ((dk >> 2) << 4) | p, 64);
+    if (dk == 16) {
+      lsum += __shfl_xor(lsum, 16, 64);
+      lsum += __shfl_xor(lsum, 32, 64);
+      l = lsum;
+    }
     if (valid) {
       const float inv = 1.f / l;
 #pragma unroll
@@ -118,7 +137,7 @@ NOISE_EXPORT int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, 
   NOISE_REQUIRE(heads > 0 && dk > 0 && dk <= 16 && heads * dk <= d_model, "noise_attn_core_fwd_f16: heads=%d d_k=%d unsupported",
                 heads, dk);
   NOISE_REQUIRE(n > 0 && ntok > 0 && ntok % n == 0, "noise_attn_core_fwd_f16: %ld tokens is not a multiple of n=%d", ntok, n);
-  Attn16Dims d{ntok, n, heads, dk, heads * dk, (n + 31) / 32 * 32, 0};
+  Attn16Dims d{ntok, n, heads, dk, heads * dk, (n + 63) / 64 * 64, 0};
   d.vp = d.n32 + 8;
   const size_t smem = ((size_t)d.n32 * 16 + (size_t)16 * d.vp) * sizeof(_Float16);
   NOISE_REQUIRE(smem <= 158 * 1024, "noise_attn_core_fwd_f16: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
