@@ -377,7 +377,7 @@ struct HeadArgs {
   float pad_value;
 };
 
-constexpr int HD_OH = 8, HD_OW = 16;
+constexpr int HD_OH = 16, HD_OW = 16;
 constexpr int HD_AH = HD_OH + 2, HD_AW = HD_OW + 2, HD_PA = HD_AH * HD_AW, HD_NTA = (HD_PA + 15) / 16;   // A0 halo tile
 constexpr int HD_XH = 2 * HD_AH + 1, HD_XW = 2 * HD_AW + 1, HD_XP = HD_XW + 1, HD_NX = HD_XH * HD_XW;     // input tile
 constexpr int HD_C0 = 32, HD_C1 = 16, HD_CP = HD_C0 + 8;
@@ -552,7 +552,7 @@ struct TailArgs {
   float bias;
 };
 
-constexpr int TL_CH = 4, TL_CW = 16;
+constexpr int TL_CH = 8, TL_CW = 16;
 constexpr int TL_UH = TL_CH + 1, TL_UW = TL_CW + 1, TL_PU = TL_UH * TL_UW, TL_NTU = (TL_PU + 15) / 16;   // u region
 constexpr int TL_SH = TL_CH + 3, TL_SW = TL_CW + 3, TL_PS = TL_SH * TL_SW;                                // s region
 constexpr int TL_CP = 32 + 8, TL_SP = 16 + 8;
@@ -700,9 +700,9 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       if (q < 3) *reinterpret_cast<float4*>(pt + pu * 12 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
-    // ---- output samples: thread = one of the 2CH x 2CW outputs of the tile
-    {
-      const int Y = tid >> 5, X = tid & 31;
+    // ---- output samples: the 2CH x 2CW outputs of the tile, 256 at a time
+    for (int oi = tid; oi < 4 * TL_CH * TL_CW; oi += 256) {
+      const int Y = oi / (2 * TL_CW), X = oi - Y * (2 * TL_CW);
       const int cy = Y >> 1, dy = Y & 1, cx = X >> 1, dx = X & 1;
       float f = a.bias;
 #pragma unroll
