@@ -81,16 +81,51 @@ __global__ __launch_bounds__((MrCfg<N2, R1, R2, FR>::NT)) void mrstft_frames_ker
   const int b = blockIdx.y, t0 = blockIdx.x * FR;
   const int hop = d.hop;
   const int nS = (FR - 1) * hop + N;
-  for (int i = tid; i < N2; i += NT) tw1[i] = tw1g[i];
-  for (int i = tid; i <= N2; i += NT) tw2[i] = tw2g[i];
-  for (int i = tid; i < N; i += NT) wn[i] = win[i];
-  for (int i = tid; i < 2 * nS; i += NT) {
-    const int which = i >= nS, ii = which ? i - nS : i;
-    int s = t0 * hop + ii - N2;                 // sample index of padded position t0*hop + ii
-    if (s < 0) s = -s;
-    if (s >= d.L) s = 2 * (d.L - 1) - s;
-    s = min(max(s, 0), d.L - 1);                // only reached by frames past T (never used)
-    xs[i] = (which ? yg : xg)[(size_t)b * d.L + s];
+  // ---- prologue: the tables and the first samples are requested before the first LDS store, the samples 8 per
+  // thread and round (one memory round trip per round instead of one per element)
+  {
+    constexpr int TWN = (N2 + NT) / NT, WNN = (N + NT - 1) / NT;
+    c32 t1r[TWN], t2r[TWN];
+    float wr[WNN];
+#pragma unroll
+    for (int u = 0; u < TWN; ++u) {
+      const int k = tid + u * NT;
+      t1r[u] = tw1g[k < N2 ? k : N2 - 1];
+      t2r[u] = tw2g[k <= N2 ? k : N2];
+    }
+#pragma unroll
+    for (int u = 0; u < WNN; ++u) wr[u] = win[min(tid + u * NT, N - 1)];
+    bool first = true;
+    for (int base = 0; base < 2 * nS; base += 8 * NT) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(base + tid + u * NT, 2 * nS - 1);
+        const int which = i >= nS, ii = which ? i - nS : i;
+        int sidx = t0 * hop + ii - N2;            // sample index of padded position t0*hop + ii
+        if (sidx < 0) sidx = -sidx;
+        if (sidx >= d.L) sidx = 2 * (d.L - 1) - sidx;
+        sidx = min(max(sidx, 0), d.L - 1);        // only reached by frames past T (never used)
+        xv[u] = (which ? yg : xg)[(size_t)b * d.L + sidx];
+      }
+      if (first) {
+        first = false;
+#pragma unroll
+        for (int u = 0; u < TWN; ++u) {
+          const int k = tid + u * NT;
+          if (k < N2) tw1[k] = t1r[u];
+          if (k <= N2) tw2[k] = t2r[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WNN; ++u)
+          if (tid + u * NT < N) wn[tid + u * NT] = wr[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + tid + u * NT;
+        if (i < 2 * nS) xs[i] = xv[u];
+      }
+    }
   }
   __syncthreads();
   const int row = tid / TPF, j = tid % TPF;
