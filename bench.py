@@ -67,7 +67,7 @@ def cpu_baseline(seconds_budget=20.0):
                 p.grad = None
         steps += 1
         el = time.perf_counter() - t0
-        if steps >= 2 and (el > seconds_budget or steps >= 20):
+        if steps >= 2 and (el > seconds_budget or steps >= 60):
             break
     # first step is warm-up-ish on CPU as well; report the steady average over all timed steps
     return {"value": round(steps * B * 0.5 / el, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
