@@ -9,7 +9,8 @@ import os
 import torch  # imported first so the HIP runtime torch ships is the one the library binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnoise_hip.so")
+# NOISE_HIP_LIB: another build of the same library (diagnostic builds with phase stamps, see scripts/dbg)
+LIB_PATH = os.environ.get("NOISE_HIP_LIB") or os.path.join(_HERE, "libnoise_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -552,6 +552,12 @@ struct TailArgs {
   float bias;
 };
 
+#ifdef FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[8];
+#define FU_T(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_fused_stamps[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define FU_T(i)
+#endif
 constexpr int TL_CH = 8, TL_CW = 16;
 constexpr int TL_UH = TL_CH + 1, TL_UW = TL_CW + 1, TL_PU = TL_UH * TL_UW, TL_NTU = (TL_PU + 15) / 16;   // u region
 constexpr int TL_SH = TL_CH + 3, TL_SW = TL_CW + 3, TL_PS = TL_SH * TL_SW;                                // s region
@@ -564,6 +570,9 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 ut[TL_NTU * 16 * TL_CP];    // u = D3 + A0 (zero outside the image)
   __shared__ __attribute__((aligned(16))) float pt[TL_NTU * 16 * 12];          // P[pixel][tap]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
+#ifdef FUSED_STAMPS
+  unsigned long long last_ = clock64();
+#endif
   const int cg = tid & 1, pl = tid >> 1;      // depthwise: 2 channel groups of 8, 128 pixel lanes
   f16x8 wdr[9], b2r;
 #pragma unroll
@@ -604,6 +613,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   uint4 prd[NIS], prs[NIS];     // raw prefetch registers: D2 and A1 pieces (8 bf16 each), summed when they are stored
   unsigned sin = 0;
   bf16x8 prea[NIA];
+  constexpr int NOUT = 4 * TL_CH * TL_CW, NIO = NOUT / 256;       // outputs of a tile, per thread
+  float plm[NIO], pmx = 1.f;    // the tile's log-magnitudes and the clip's normaliser, requested with the tile's inputs
   const int ntiles = a.B * a.tiles_y * a.tiles_x;      // < 2^31 (checked by the launcher)
   int nb = 0, ncy0 = 0, ncx0 = 0;                      // origin of the prefetched tile
   auto prefetch = [&](int tile) {
@@ -634,13 +645,26 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       ix = ix < a.w ? ix : a.w - 1;
       prea[u] = *reinterpret_cast<const bf16x8*>(a0b + (iy * a.Ws0 + ix) * 32 + c8);
     }
+    if (a.enh) {
+      pmx = a.absmax[b];
+#pragma unroll
+      for (int u = 0; u < NIO; ++u) {
+        const int oi = tid + 256 * u, Y = oi / (2 * TL_CW), X = oi - Y * (2 * TL_CW);
+        int y = 2 * cy0 + Y - a.offy, x = 2 * cx0 + X - a.offx;
+        y = min(max(y, 0), a.H - 1);
+        x = min(max(x, 0), a.W - 1);
+        plm[u] = a.logmag[((size_t)b * a.H + y) * a.W + x];
+      }
+    }
   };
   // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
   int tile = xcd_chunked_block();
   if (tile < ntiles) prefetch(tile);
   __syncthreads();
+  FU_T(0);
   for (; tile < ntiles; tile += gridDim.x) {
     const int b = nb, cy0 = ncy0, cx0 = ncx0;
+    FU_T(6);
 #pragma unroll
     for (int u = 0; u < NIS; ++u)
       if (sld[u] >= 0) {
@@ -657,8 +681,14 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 #pragma unroll
     for (int u = 0; u < NIA; ++u)
       if (ald[u] >= 0) *reinterpret_cast<bf16x8*>(a0t + ald[u]) = prea[u];
+    float clm[NIO];
+#pragma unroll
+    for (int u = 0; u < NIO; ++u) clm[u] = plm[u];
+    const float cmx = pmx + 1e-6f;
     __syncthreads();
+    FU_T(1);
     if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    FU_T(2);
 
     // ---- depthwise ConvTranspose2d 3x3 stride 1: out[o] = sum_k s[o + 1 - k] w[k]
     for (int pu = pl; pu < TL_PU; pu += 128) {
@@ -673,6 +703,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       *reinterpret_cast<f16x8*>(h2 + pu * TL_CP + 8 * cg) = clamp01_h8(acc);
     }
     __syncthreads();
+    FU_T(3);
     // ---- 1x1 16 -> 32, + A0: u (zero outside the image: the transposed convolution only sees real pixels)
     for (int nt = wave; nt < TL_NTU; nt += 4) {
       const int pu = 16 * nt + p;
@@ -691,6 +722,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       }
     }
     __syncthreads();
+    FU_T(4);
     // ---- P[pixel][tap]
     for (int nt = wave; nt < TL_NTU; nt += 4) {
       const int pu = 16 * nt + p;
@@ -700,8 +732,11 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       if (q < 3) *reinterpret_cast<float4*>(pt + pu * 12 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
+    FU_T(5);
     // ---- output samples: the 2CH x 2CW outputs of the tile, 256 at a time
-    for (int oi = tid; oi < 4 * TL_CH * TL_CW; oi += 256) {
+#pragma unroll
+    for (int u = 0; u < NIO; ++u) {
+      const int oi = tid + 256 * u;
       const int Y = oi / (2 * TL_CW), X = oi - Y * (2 * TL_CW);
       const int cy = Y >> 1, dy = Y & 1, cx = X >> 1, dx = X & 1;
       float f = a.bias;
@@ -719,10 +754,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
         const size_t o = ((size_t)b * a.H + y) * a.W + x;
         if (a.filt) a.filt[o] = f;
-        if (a.enh) {
-          const float mx = a.absmax[b] + 1e-6f;
-          a.enh[o] = fminf(fmaxf(a.logmag[o] / mx + f, -1.f), 1.f) * mx;
-        }
+        if (a.enh) a.enh[o] = fminf(fmaxf(clm[u] / cmx + f, -1.f), 1.f) * cmx;
       }
     }
     // the next iteration's first barrier separates these reads of pt from the next writes (pt is written after 3 more)
@@ -730,6 +762,16 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 }
 
 }  // namespace
+
+#ifdef FUSED_STAMPS
+NOISE_EXPORT int noise_debug_fused_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[8] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), 8 * sizeof(unsigned long long));
+}
+#endif
 
 // Padded weight shapes the fused kernels expect (so that a binding can size its buffers); "half" = IEEE binary16:
 //   w1 [ceil(Hid/16)*16][roundup(Cin,32)] half, b1 [ceil(Hid/16)*16] f32, wd [9][ceil(Hid/8)*8] half (tap-major),
