@@ -191,8 +191,9 @@ int noise_fused_ir_block(const void* x, const void* skip, int in_f32, int Hs, in
 
 /* Head of the fused network: normalise (models.py:614-622) + left/top pad (:589) -> first Conv2d 1->32 s2 + BN + ReLU6
  * (:1151-1159; kept as skip tensor a0) -> depthwise 3x3 s1 + BN + ReLU6 -> 1x1 32->16 + BN (:385-396; skip tensor a1).
- * w0 [32][32] half: row c = folded taps 0..7 of channel c at k = 0..7 and again at k = 8..15, tap 8 at k = 16 and 17
- * (the kernel multiplies the half-rounded input and its rounding remainder), zeros after; wd [9][32], b2 [32] half;
+ * w0 [32][32] half: row c = folded tap 4q + t of channel c at k = 8q + 2t and again at k = 8q + 2t + 1 (q < 3, t < 4,
+ * 4q + t <= 8; the kernel multiplies the half-rounded input and its rounding remainder), zeros elsewhere; wd [9][32],
+ * b2 [32] half;
  * w3 [16][32] half.  a0 [B][H1][W1][32], a1 [B][H1][W1][16] bf16, H1 = (H + hp - 1)/2 + 1, W1 likewise. */
 int noise_fused_head(const float* logmag, const float* absmax, const void* w0, const float* b0, const void* wd,
                      const void* b2, const void* w3, const float* b3, void* a0, void* a1, int B, int H, int W, int hp,

@@ -359,9 +359,10 @@ int launch_ir(const IrArgs& a0, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------------------
 // Head: normalise + left/top pad (models.py:614-622, :589) -> first Conv2d 1->32 k3 s2 + BN + ReLU6 (:1151-1159, kept as
 // skip tensor A0) -> block 1: depthwise 3x3 s1 + BN + ReLU6 -> 1x1 32->16 + BN (:385-396, skip tensor A1).
-// The single-channel 3x3 convolution runs on the matrix cores as a K = 32 product: k = 0..7 holds taps 0..7 of the input
-// rounded to half, k = 8..15 their rounding remainders, k = 16 / 17 tap 8 and its remainder.  The input keeps ~22
-// significant bits that way; only the weights are rounded, like everywhere else.
+// The single-channel 3x3 convolution runs on the matrix cores as a K = 32 product: reduction slot k = 8q + 2t + s holds
+// tap 4q + t of the input (q < 3, t < 4, taps past 8 unused), rounded to half for s = 0 and the rounding remainder for
+// s = 1, so lane group q of the B operand touches only its own taps.  The input keeps ~22 significant bits that way;
+// only the weights are rounded, like everywhere else.
 struct HeadArgs {
   const float* logmag;    // [B][H][W]
   const float* absmax;    // [B]
@@ -377,6 +378,12 @@ struct HeadArgs {
   float pad_value;
 };
 
+#ifdef FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[16];
+#define FU_T(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_fused_stamps[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define FU_T(i)
+#endif
 constexpr int HD_OH = 16, HD_OW = 16;
 constexpr int HD_AH = HD_OH + 2, HD_AW = HD_OW + 2, HD_PA = HD_AH * HD_AW, HD_NTA = (HD_PA + 15) / 16;   // A0 halo tile
 constexpr int HD_XH = 2 * HD_AH + 1, HD_XW = 2 * HD_AW + 1, HD_XP = HD_XW + 1, HD_NX = HD_XH * HD_XW;     // input tile
@@ -407,6 +414,12 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   for (int i = tid; i < HD_NTA * 16 * HD_CP / 8; i += 256) reinterpret_cast<uint4*>(h1)[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < HD_POUT * HD_CP / 8; i += 256) reinterpret_cast<uint4*>(h2)[i] = make_uint4(0, 0, 0, 0);
 
+  int toff[4];                   // LDS offsets of this lane group's four taps of the 3x3 window (clamped to tap 8)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tap = min(4 * q + t, 8);
+    toff[t] = (tap / 3) * HD_XP + tap % 3;
+  }
   const int Hp = a.H + a.hp, Wp = a.W + a.wp;
   constexpr int NI = (HD_NX + 255) / 256;
   int pry[NI], prx[NI];
@@ -445,8 +458,12 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   int tile = xcd_chunked_block();
   if (tile < ntiles) prefetch(tile);
   __syncthreads();
+#ifdef FUSED_STAMPS
+  unsigned long long last_ = clock64();
+#endif
   for (; tile < ntiles; tile += gridDim.x) {
     const int b = nb, oy0 = noy0, ox0 = nox0;
+    FU_T(13);
     {
       const float inv = 1.f / (pre_amax + 1e-6f);
 #pragma unroll
@@ -455,7 +472,9 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
           xs[pry[u] * HD_XP + prx[u]] = (freal >> u) & 1u ? pre[u] * inv : ((finside >> u) & 1u ? a.pad_value : 0.f);
     }
     __syncthreads();
+    FU_T(8);
     if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    FU_T(9);
 
     // ---- first conv on the A0 halo tile
     for (int nt = wave; nt < HD_NTA; nt += 4) {
@@ -465,18 +484,15 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       const bool valid = pi < HD_PA && (unsigned)ay < (unsigned)a.H1 && (unsigned)ax < (unsigned)a.W1;
       const float m = valid ? 1.f : 0.f;
       const float* xp = xs + (pi < HD_PA ? 2 * ry * HD_XP + 2 * rx : 0);
-      _Float16 hi[9], lo[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float v = xp[(t / 3) * HD_XP + t % 3];
-        hi[t] = (_Float16)v;
-        lo[t] = (_Float16)(v - (float)hi[t]);
-      }
+      // reduction slot 8q + 2t + s = tap 4q + t, rounded to half (s = 0) and its remainder (s = 1): the fp32 input keeps
+      // ~22 bits through the half-precision MFMA; slots past tap 8 meet zero weights
       f16x8 xv;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const _Float16 third = j == 0 ? hi[8] : (j == 1 ? lo[8] : (_Float16)0.f);
-        xv[j] = q == 0 ? hi[j] : (q == 1 ? lo[j] : (q == 2 ? third : (_Float16)0.f));
+      for (int t = 0; t < 4; ++t) {
+        const float v = xp[toff[t]];
+        const _Float16 hi = (_Float16)v;
+        xv[2 * t] = hi;
+        xv[2 * t + 1] = (_Float16)(v - (float)hi);
       }
       __bf16* a0p = a.a0 + (((size_t)b * a.H1 + ay) * a.W1 + ax) * HD_C0 + 4 * q;
       const bool interior = valid && ry >= 1 && ry <= HD_OH && rx >= 1 && rx <= HD_OW;
@@ -499,6 +515,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       }
     }
     __syncthreads();
+    FU_T(10);
     // ---- depthwise 3x3 stride 1 on A0
     for (int po = pl; po < HD_POUT; po += 64) {
       const int oy = po >> 4, ox = po & 15;
@@ -512,6 +529,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       *reinterpret_cast<f16x8*>(h2 + po * HD_CP + 8 * cg) = clamp01_h8(acc);
     }
     __syncthreads();
+    FU_T(11);
     // ---- project 32 -> 16
     for (int nt = wave; nt < HD_NT3; nt += 4) {
       const int po = 16 * nt + p;
@@ -552,12 +570,6 @@ struct TailArgs {
   float bias;
 };
 
-#ifdef FUSED_STAMPS
-__device__ unsigned long long g_fused_stamps[8];
-#define FU_T(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_fused_stamps[i] += now_ - last_; last_ = now_; } } while (0)
-#else
-#define FU_T(i)
-#endif
 constexpr int TL_CH = 8, TL_CW = 16;
 constexpr int TL_UH = TL_CH + 1, TL_UW = TL_CW + 1, TL_PU = TL_UH * TL_UW, TL_NTU = (TL_PU + 15) / 16;   // u region
 constexpr int TL_SH = TL_CH + 3, TL_SW = TL_CW + 3, TL_PS = TL_SH * TL_SW;                                // s region
@@ -766,10 +778,10 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 #ifdef FUSED_STAMPS
 NOISE_EXPORT int noise_debug_fused_stamps(unsigned long long* out, int reset) {
   if (reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, sizeof(z));
   }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), 8 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), 16 * sizeof(unsigned long long));
 }
 #endif
 
@@ -817,8 +829,8 @@ NOISE_EXPORT int noise_fused_ir_block(const void* x, const void* skip, int in_f3
   return 0;
 }
 
-// Head of the fused network (see head_kernel).  w0 [32][32] half: row c holds taps 0..7 of output channel c at
-// k = 0..7 and again at k = 8..15, tap 8 at k = 16 and k = 17, zeros after; wd [9][32] half, b2 [32] half,
+// Head of the fused network (see head_kernel).  w0 [32][32] half: row c holds tap 4q + t of output channel c at
+// k = 8q + 2t and again at k = 8q + 2t + 1 (q < 3, t < 4, 4q + t <= 8), zeros elsewhere; wd [9][32] half, b2 [32] half,
 // w3 [16][32] half.  a0 [B][H1][W1][32], a1 [B][H1][W1][16] bf16 with H1 = (H + hp - 1)/2 + 1, W1 = (W + wp - 1)/2 + 1.
 NOISE_EXPORT int noise_fused_head(const float* logmag, const float* absmax, const void* w0, const float* b0,
                                   const void* wd, const void* b2, const void* w3, const float* b3, void* a0, void* a1,

@@ -100,8 +100,15 @@ class HeadWeights:
         s0, sh0 = bn_fold(first[1])
         w0 = first[0].weight.detach().float().view(32, 9) * s0[:, None] / 6.0     # hidden activations are kept / 6
         sh0 = sh0 / 6.0
-        # k = 0..7: taps 0..7 (for the rounded input), k = 8..15: taps 0..7 again (for its remainder), k = 16, 17: tap 8
-        self.w0 = pad_matrix(torch.cat([w0[:, :8], w0[:, :8], w0[:, 8:], w0[:, 8:]], dim=1), 32, 32, torch.float16)
+        # reduction slot k = 8q + 2t + s is tap 4q + t (zero weight past tap 8), s = 0 for the input rounded to half and
+        # s = 1 for its remainder: lane group q of the MFMA B operand then reads only its own four taps
+        wk = torch.zeros(32, 32, dtype=torch.float32, device=w0.device)
+        for q in range(4):
+            for t in range(4):
+                if 4 * q + t < 9:
+                    wk[:, 8 * q + 2 * t] = w0[:, 4 * q + t]
+                    wk[:, 8 * q + 2 * t + 1] = w0[:, 4 * q + t]
+        self.w0 = pad_matrix(wk, 32, 32, torch.float16)
         self.b0 = sh0.contiguous()
         s2, sh2 = bn_fold(seq[0][1])
         s3, sh3 = bn_fold(seq[2])

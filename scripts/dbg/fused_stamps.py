@@ -29,10 +29,16 @@ with torch.no_grad():
     for _ in range(n):
         m(x)
     torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 _lib.lib.noise_debug_fused_stamps(out, 0)
 names = ["prologue", "stage-in + barrier", "prefetch issue", "depthwise + barrier", "project + barrier", "tap MFMA + barrier",
          "output gather"]
+print("tail kernel")
 tot = sum(out[i] for i in range(7))
 for i, nm in enumerate(names):
+    print(f"   {nm:22s} {out[i] / n:10.0f} ticks  {100.0 * out[i] / max(tot, 1):5.1f} %")
+print("head kernel")
+hn = {8: "stage-in + barrier", 9: "prefetch issue", 10: "first conv + barrier", 11: "depthwise + barrier", 13: "project (+ loop top)"}
+tot = sum(out[i] for i in hn)
+for i, nm in hn.items():
     print(f"   {nm:22s} {out[i] / n:10.0f} ticks  {100.0 * out[i] / max(tot, 1):5.1f} %")
