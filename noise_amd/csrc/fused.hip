@@ -21,6 +21,16 @@
 
 namespace {
 
+// Diagnostic build (-DFUSED_STAMPS, scripts/dbg/fused_stamps.py): cycles one workgroup spends per phase.
+#ifdef FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[32];
+#define FU_T(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_fused_stamps[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define FU_T(i)
+#endif
+#define IR_T(i) do { if ((CIN == 24 && TR) || (CIN == 16 && !TR)) FU_T((TR ? 16 : 24) + (i)); } while (0)
+
+
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -198,8 +208,12 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
   int tile = xcd_chunked_block();
   if (tile < ntiles) prefetch(tile);
   __syncthreads();
+#ifdef FUSED_STAMPS
+  unsigned long long last_ = clock64();
+#endif
   for (; tile < ntiles; tile += gridDim.x) {
     const int b = nb, y0 = ny0, x0 = nx0;
+    IR_T(5);
     // ---- registers -> input tile (+ the pixel mask, written by the thread that holds a pixel's first piece)
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
@@ -217,7 +231,9 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
       }
     }
     __syncthreads();
+    IR_T(0);
     if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    IR_T(1);
 
     // ---- expand: h1[pixel][hidden] = relu6(W1 x + b1), zero outside the image (the depthwise padding)
     {
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
       }
     }
     __syncthreads();
+    IR_T(2);
 
     // ---- depthwise 3x3 (stride 2) or its transpose on the hidden tile, + bias, ReLU6 (packed half arithmetic)
     if (pl < NPL) {
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
       }
     }
     __syncthreads();
+    IR_T(3);
 
     // ---- project: out[pixel][cout] = W3 h2 + b3 (no activation)
     {
@@ -378,12 +396,6 @@ struct HeadArgs {
   float pad_value;
 };
 
-#ifdef FUSED_STAMPS
-__device__ unsigned long long g_fused_stamps[16];
-#define FU_T(i) do { if (blockIdx.x == 8 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_fused_stamps[i] += now_ - last_; last_ = now_; } } while (0)
-#else
-#define FU_T(i)
-#endif
 constexpr int HD_OH = 16, HD_OW = 16;
 constexpr int HD_AH = HD_OH + 2, HD_AW = HD_OW + 2, HD_PA = HD_AH * HD_AW, HD_NTA = (HD_PA + 15) / 16;   // A0 halo tile
 constexpr int HD_XH = 2 * HD_AH + 1, HD_XW = 2 * HD_AW + 1, HD_XP = HD_XW + 1, HD_NX = HD_XH * HD_XW;     // input tile
@@ -778,10 +790,10 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 #ifdef FUSED_STAMPS
 NOISE_EXPORT int noise_debug_fused_stamps(unsigned long long* out, int reset) {
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, sizeof(z));
   }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), 16 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), 32 * sizeof(unsigned long long));
 }
 #endif
 

@@ -29,7 +29,7 @@ with torch.no_grad():
     for _ in range(n):
         m(x)
     torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 _lib.lib.noise_debug_fused_stamps(out, 0)
 names = ["prologue", "stage-in + barrier", "prefetch issue", "depthwise + barrier", "project + barrier", "tap MFMA + barrier",
          "output gather"]
@@ -42,3 +42,9 @@ hn = {8: "stage-in + barrier", 9: "prefetch issue", 10: "first conv + barrier", 
 tot = sum(out[i] for i in hn)
 for i, nm in hn.items():
     print(f"   {nm:22s} {out[i] / n:10.0f} ticks  {100.0 * out[i] / max(tot, 1):5.1f} %")
+for base, title in ((16, "decoder block 24 -> 72 -> 16 (transposed)"), (24, "encoder block 16 -> 48 -> 24")):
+    print(title)
+    nm = {0: "stage-in + barrier", 1: "prefetch issue", 2: "expand + barrier", 3: "depthwise + barrier", 5: "project + stores"}
+    tot = sum(out[base + i] for i in nm)
+    for i, name in nm.items():
+        print(f"   {name:22s} {out[base + i] / n:10.0f} ticks  {100.0 * out[base + i] / max(tot, 1):5.1f} %")
