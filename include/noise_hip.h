@@ -74,6 +74,16 @@ int noise_istft_bwd_fft(const float* d_wave, const float* wave_out, const float*
                         const float* syn_window, const float* tw1, const float* tw2, const float* window_sum,
                         float* d_logmag, int accumulate, int B, int T, int n_fft, int hop, void* stream);
 
+/* Projection of a transposed inverted-residual block without its depthwise output in memory (models.py:299-345,
+ * :385-396): out (B, 2Hi-1, 2Wi-1, N) raw = act_dw(bn_dw(ConvTranspose2d_dw3x3s2(act_in(bn_in(in))))) x W^T with in
+ * (B, Hi, Wi, K) raw, wdw (K, 1, 3, 3), W (N, K); *_coef = [scale(K) | shift(K) | ...] or NULL.  Same arithmetic and
+ * summation order as noise_dw3x3_fwd (transposed) followed by noise_pw_fwd.  Served: (K, N) = (72, 16), (96, 24),
+ * (192, 32), the decoder blocks of spectralv2.yaml.  stats_slab as noise_pw_fwd (<= 1024 rows). */
+int noise_pw_fwd_virt_supported(int K, int N);
+int noise_pw_fwd_virt(const float* in_y, const float* in_coef, int in_relu6, const float* wdw, const float* dw_coef,
+                      int dw_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, int B, int Hi, int Wi,
+                      int K, int N, void* stream);
+
 /* ---- loss of the waveform models (train/models.py:641-720) ------------------------------------------------------ */
 /* One resolution of Base.multi_resolution_stft_loss (:700-720) with Base.stft_mag (:687-698): torch.stft semantics
  * (reflect-padded centred frames, T = 1 + L/hop, window of win_length samples centred in n_fft), magnitudes clamped at

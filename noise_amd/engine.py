@@ -10,6 +10,8 @@ producer's BatchNorm(+ReLU6) while loading ("lazy" sources), and each conv kerne
 per-channel sums that the BatchNorm of its own output needs, so an activation is written once and
 read once per consumer.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -179,6 +181,8 @@ class DenoiserPlan:
         self.att_slab_post = torch.empty(ATTN_MAX_BLOCKS * (2 * D * D + D * hd + 7 * D + 1), **f32)
         self.att_slab_pre = torch.empty(ATTN_MAX_BLOCKS * (3 * hd * D + 2 * D), **f32)
         self.bwd_ready = False
+        # eval forwards skip materialising the output of stride-2 transposed depthwise layers (NOISE_VIRTUAL_DW=0: keep it)
+        self.virtual_dw = os.environ.get("NOISE_VIRTUAL_DW", "1") != "0"
 
     # -------------------------------------------------------------------------------- backward buffers
     def ensure_backward_buffers(self):
@@ -268,7 +272,24 @@ class DenoiserPlan:
                 ops.crop_nhwc(skip[0], win, oy, ox)
                 skip = (win, skip[1], skip[2])
             first = True
+            virt = None
             for r in layers:
+                if virt is not None:
+                    # projection of a transposed block: the depthwise output is rebuilt inside the 1x1 convolution
+                    dw, virt = virt, None
+                    r.src_a, r.src_b = dw.lazy(), None
+                    ops.pw_fwd_virt(dw.src_a, dw.conv.weight, dw.coef, dw.relu6, r.conv.weight, r.y, None, dw.B, dw.Hi,
+                                    dw.Wi, r.Cin, r.C)
+                    self._bn(r, 0, training)
+                    cur = r.lazy()
+                    continue
+                if (self.virtual_dw and not training and not first and r.kind == "dw" and r.transposed
+                        and tuple(r.stride) == (2, 2) and ops.pw_fwd_virt_supported(r.C, layers[-1].C)):
+                    # eval forward: nothing reads the depthwise output but the projection that follows it
+                    r.src_a, r.src_b = cur, None
+                    self._bn(r, 0, training)
+                    virt = r
+                    continue
                 if r.kind == "last":
                     r.src_a, r.src_b = cur, skip
                     ops.last_convT_fwd(cur, skip, r.conv.weight, r.conv.bias, logmag, absmax, self.enh, None, r.B, r.Hi,

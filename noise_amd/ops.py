@@ -26,6 +26,8 @@ _lib.register({
     "noise_bn_coef_eval": [_I, _P, _P, _P, _P, _F, _P, _P],
     "noise_bn_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "noise_pw_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
+    "noise_pw_fwd_virt_supported": [_I, _I],
+    "noise_pw_fwd_virt": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "noise_pw_dgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "noise_pw_wgrad": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_pw_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
@@ -155,6 +157,20 @@ def pw_fwd(a, b, w, out, slab, npix, K, N):
     rows = ctypes.c_int(0)
     _lib.call("noise_pw_fwd", *_src(a), *_src(b), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows), npix, K, N,
               _lib.stream(), nbytes=4 * npix * (K * _nsrc(b) + N))
+    return rows.value
+
+
+def pw_fwd_virt_supported(K, N):
+    return bool(_lib.lib.noise_pw_fwd_virt_supported(K, N))
+
+
+def pw_fwd_virt(src, wdw, dw_coef, dw_relu6, w, out, slab, B, Hi, Wi, K, N):
+    """Projection of a transposed block straight from the depthwise layer's input `src` (lazy source): the depthwise
+    output (B, 2Hi-1, 2Wi-1, K) is rebuilt on the fly and never touches HBM."""
+    rows = ctypes.c_int(0)
+    npix = B * (2 * Hi - 1) * (2 * Wi - 1)
+    _lib.call("noise_pw_fwd_virt", *_src(src), ptr(wdw), ptr(dw_coef), int(dw_relu6), ptr(w), ptr(out), ptr(slab),
+              ctypes.byref(rows), B, Hi, Wi, K, N, _lib.stream(), nbytes=4 * (B * Hi * Wi * K + npix * N))
     return rows.value
 
 

@@ -131,6 +131,38 @@ def test_depthwise(dev, C, stride, transposed, two_src, shape):
     close(dw, w.grad, 1e-4, "wgrad (epilogue run)")
 
 
+@pytest.mark.parametrize("K,N,shape", [(72, 16, (2, 41, 17)), (96, 24, (3, 6, 4)), (192, 32, (2, 11, 5)), (72, 16, (1, 1, 1)),
+                                       (72, 16, (5, 7, 1)), (96, 24, (2, 1, 9))])
+def test_pointwise_virtual_source(dev, K, N, shape):
+    """The projection of a transposed block computed straight from the depthwise layer's input (the depthwise output is
+    rebuilt on the fly) equals the two stand-alone kernels bit for bit, statistics included."""
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(K + shape[1])
+    B, Hi, Wi = shape
+    y_in = nhwc(torch.randn(B, K, Hi, Wi, generator=g)).to(dev)
+    c_in = rand_coef(K, g).to(dev)
+    c_dw = rand_coef(K, g).to(dev)
+    wdw = (torch.randn(K, 1, 3, 3, generator=g) * 0.4).to(dev)
+    w = (torch.randn(N, K, 1, 1, generator=g) * 0.2).to(dev)
+    Ho, Wo = 2 * Hi - 1, 2 * Wi - 1
+    y_dw = torch.empty(B, Ho, Wo, K, device=dev)
+    ops.dw3x3_fwd((y_in, c_in, True), None, wdw, y_dw, None, True, B, Hi, Wi, K, (2, 2))
+    ref = torch.empty(B, Ho, Wo, N, device=dev)
+    slab_r = torch.zeros(1024 * 2 * N, device=dev)
+    rows_r = ops.pw_fwd((y_dw, c_dw, True), None, w, ref, slab_r, B * Ho * Wo, K, N)
+    out = torch.full((B, Ho, Wo, N), float("nan"), device=dev)
+    slab = torch.zeros(1024 * 2 * N, device=dev)
+    assert ops.pw_fwd_virt_supported(K, N)
+    rows = ops.pw_fwd_virt((y_in, c_in, True), wdw, c_dw, True, w, out, slab, B, Hi, Wi, K, N)
+    assert torch.equal(out, ref)
+    a1, a2 = slab_stats(slab, rows, N)
+    b1, b2 = slab_stats(slab_r, rows_r, N)
+    close(a1, b1, 1e-5, "sum")
+    close(a2, b2, 1e-5, "sumsq")
+    with pytest.raises(RuntimeError):
+        ops.pw_fwd_virt((y_in, c_in, True), wdw, c_dw, True, w, out, slab, B, Hi, Wi, 48, N)
+
+
 def check_epilogue(g_in, scratch, rows, row_stride, col0, g_ref_nchw, ya_nchw, ca, relu_a, C):
     v = ya_nchw * ca[:C].view(1, C, 1, 1) + ca[C:2 * C].view(1, C, 1, 1)
     mask = ((v > 0) & (v < 6)).float() if relu_a else torch.ones_like(v)
