@@ -83,6 +83,15 @@ int noise_pw_fwd_virt_supported(int K, int N);
 int noise_pw_fwd_virt(const float* in_y, const float* in_coef, int in_relu6, const float* wdw, const float* dw_coef,
                       int dw_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, int B, int Hi, int Wi,
                       int K, int N, void* stream);
+/* Backward of noise_pw_fwd_virt (fused as noise_pw_bwd): g_in (B, 2Hi-1, 2Wi-1, K) = gradient of the activated
+ * depthwise output masked by the depthwise ReLU6; stats_slab rows [sum g | sum g*xhat] (2K floats) for the depthwise
+ * BatchNorm backward; scratch rows of N*K floats with the per-workgroup weight gradient (*slab_rows rows of each, at
+ * most noise_pw_bwd_max_rows(N, K)).  dz / y_out / coef3: lazy gradient of the projection output (coef3 NULL: dz is
+ * dL/dy).  dw_coef: [scale | shift | mean | invstd | mean_lo] of the depthwise BatchNorm (required). */
+int noise_pw_bwd_virt(const float* dz, const float* y_out, const float* coef3, const float* in_y, const float* in_coef,
+                      int in_relu6, const float* wdw, const float* dw_coef, int dw_relu6, const float* w, float* g_in,
+                      float* scratch, float* stats_slab, int* slab_rows, int B, int Hi, int Wi, int K, int N,
+                      void* stream);
 
 /* ---- loss of the waveform models (train/models.py:641-720) ------------------------------------------------------ */
 /* One resolution of Base.multi_resolution_stft_loss (:700-720) with Base.stft_mag (:687-698): torch.stft semantics

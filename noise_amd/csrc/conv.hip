@@ -521,7 +521,10 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
   if (check_c("noise_dw3x3_fwd", C)) return -1;
   NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "noise_dw3x3_fwd: empty input");
   NOISE_REQUIRE((sy == 1 || sy == 2) && (sx == 1 || sx == 2), "noise_dw3x3_fwd: stride must be 1 or 2");
-  NOISE_REQUIRE(a_y && w && out, "noise_dw3x3_fwd: null pointer");
+  // out == NULL: statistics only (stride-2 transposed layers whose output the following 1x1 layer rebuilds)
+  NOISE_REQUIRE(a_y && w, "noise_dw3x3_fwd: null pointer");
+  NOISE_REQUIRE(out || (transposed && sy == 2 && sx == 2 && stats_slab),
+                "noise_dw3x3_fwd: out may only be NULL for a stride-2 transposed layer with a statistics slab");
   ConvDims d;
   d.B = B; d.Hi = Hi; d.Wi = Wi; d.C = C; d.sy = sy; d.sx = sx;
   d.Ho = transposed ? (Hi - 1) * sy + 1 : (Hi - 1) / sy + 1;
@@ -545,7 +548,12 @@ NOISE_EXPORT int noise_dw3x3_fwd(const float* a_y, const float* a_coef, int a_re
     else                                                                                                           \
       NOISE_LAUNCH_ROUNDS((__VA_ARGS__ false>), grid, smem, st, A, Bs, w, out, stats_slab, wd);         \
   } while (0)
-    if (cell)
+    if (cell && out == nullptr) {
+      if (hb)
+        NOISE_LAUNCH_ROUNDS((walk_cell_fwd_kernel<true, false>), grid, smem, st, A, Bs, w, out, stats_slab, wd);
+      else
+        NOISE_LAUNCH_ROUNDS((walk_cell_fwd_kernel<false, false>), grid, smem, st, A, Bs, w, out, stats_slab, wd);
+    } else if (cell)
       LAUNCH_FWD(walk_cell_fwd_kernel<);
     else if (transposed)
       LAUNCH_FWD(walk_gather_fwd_kernel<1, true,);

@@ -10,7 +10,11 @@
 // Output pixel (2m + py, 2x + px) takes source cells (m, x), (m, x + px), (m + py, x), (m + py, x + px) with the taps
 // and in the summation order of the stand-alone depthwise kernel (walk_cell_fwd_kernel), so both agree bit for bit.
 // MFMA arrangement, weight fragments, prefetch and statistics epilogue are those of pw_gemm_kernel (pw.hip).
+#include <type_traits>
+
 #include "lazy.h"
+
+extern "C" int noise_pw_bwd_max_rows(int Cout, int Cin);   // pw.hip
 
 namespace {
 
@@ -18,29 +22,95 @@ struct VirtDims {
   long npix;            // B * Ho * Wo output pixels
   int K, N;             // hidden channels (multiple of 8), output channels (multiple of 4)
   int Hi, Wi, Ho, Wo;   // source and output image sizes, Ho = 2 Hi - 1, Wo = 2 Wi - 1
+  long ncells;          // B * Hi * Wi source pixels
 };
 
-// tap index of the stand-alone kernel for each (parity, source) pair; -1: the source does not contribute
-__device__ __forceinline__ int virt_tap(int py, int px, int src) {
-  // src 0 = (m, x), 1 = (m, x+1), 2 = (m+1, x), 3 = (m+1, x+1)
-  if (src == 0) return py ? (px ? 8 : 7) : (px ? 5 : 4);
-  if (src == 1) return px ? (py ? 6 : 3) : -1;
-  if (src == 2) return py ? (px ? 2 : 1) : -1;
-  return (px && py) ? 0 : -1;
-}
+// Tiles of 16 consecutive source cells.  The position of a tile's first cell is kept as (image, row, column) and
+// advanced by the grid stride without a division (uniform values).  A tile past the end keeps the position of the last
+// one it passed: its loads stay in bounds and its cells do not "exist".
+struct TilePos {
+  long tile;
+  int b, m, x;
+};
+struct CellTiles {
+  long ncells, ntiles;
+  int Hi, Wi;
+  int sb, sm, sx;   // 16 * gridDim.x cells as (images, rows, columns)
+  __device__ __forceinline__ CellTiles(const VirtDims& d) {
+    ncells = d.ncells;
+    ntiles = (ncells + 15) >> 4;
+    Hi = d.Hi;
+    Wi = d.Wi;
+    const unsigned per_src = (unsigned)Hi * (unsigned)Wi, step = 16u * gridDim.x;
+    sb = (int)(step / per_src);
+    const unsigned rem = step - (unsigned)sb * per_src;
+    sm = (int)(rem / (unsigned)Wi);
+    sx = (int)(rem - (unsigned)sm * (unsigned)Wi);
+  }
+  __device__ __forceinline__ TilePos pos(long tile) const {
+    const long tl = tile < ntiles ? tile : ntiles - 1;
+    const unsigned c0 = (unsigned)(tl * 16), per_src = (unsigned)Hi * (unsigned)Wi;
+    TilePos t;
+    t.tile = tile;
+    t.b = (int)(c0 / per_src);
+    const unsigned rem = c0 - (unsigned)t.b * per_src;
+    t.m = (int)(rem / (unsigned)Wi);
+    t.x = (int)(rem - (unsigned)t.m * (unsigned)Wi);
+    return t;
+  }
+  __device__ __forceinline__ void advance(TilePos& t) const {
+    t.tile += gridDim.x;
+    if (t.tile >= ntiles) return;
+    t.x += sx;
+    if (t.x >= Wi) {
+      t.x -= Wi;
+      ++t.m;
+    }
+    t.m += sm;
+    if (t.m >= Hi) {
+      t.m -= Hi;
+      ++t.b;
+    }
+    t.b += sb;
+  }
+  // cell i of a tile (clamped to the last cell): image, row, column; returns whether the cell exists
+  __device__ __forceinline__ bool cell(const TilePos& t, int i, int& b, int& m, int& x) const {
+    const long tl = t.tile < ntiles ? t.tile : ntiles - 1;
+    const bool exists = t.tile < ntiles && tl * 16 + i < ncells;
+    const int last = (int)(ncells - 1 - tl * 16);
+    b = t.b;
+    m = t.m;
+    x = t.x + (i < last ? i : last);
+    while (x >= Wi) {
+      x -= Wi;
+      ++m;
+    }
+    while (m >= Hi) {
+      m -= Hi;
+      ++b;
+    }
+    return exists;
+  }
+};
 
-template <int KC, int MT>
-__global__ __launch_bounds__(256) void pw_virt_fwd_kernel(LazySrc In, const float* __restrict__ wdw, LazySrc Dw,
-                                                          const float* __restrict__ W, float* __restrict__ out,
-                                                          float* __restrict__ slab, VirtDims d) {
+// Forward.  A workgroup walks tiles of 16 consecutive source cells; each of its four waves takes one parity class
+// (py, px) of the 64 output pixels a tile produces, rotating with the tile so that the classes' unequal work (1, 2, 2
+// and 4 source cells per output pixel) evens out.  Lane (p, q) builds the MFMA operand of output pixel (2m + py, 2x + px)
+// of cell p directly in registers (channels 16 jj + 4 q .. + 3), so nothing is staged through LDS.  The K channels are
+// processed in KH chunks of KCH 16-channel tiles: the raw source cells of the next chunk are requested before the MFMAs
+// of the current one.
+template <int KCH, int KH, int MT>
+__global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const float* __restrict__ wdw, LazySrc Dw,
+                                                             const float* __restrict__ W, float* __restrict__ out,
+                                                             float* __restrict__ slab, VirtDims d) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, q = lane >> 4;
   const int K = d.K, N = d.N;
-  constexpr int KP = KC * 16;
+  constexpr int KC = KCH * KH, KP = KC * 16;
   float* wfrag = lds;                    // [MT][KC][64][4]
   float* cf = wfrag + MT * KC * 256;     // [4][KP]: scale_in, shift_in, scale_dw, shift_dw
-  float* wt = cf + 4 * KP;               // [10][KP]: the 9 taps (tap-major), row 9 = zeros (absent source)
+  float* wt = cf + 4 * KP;               // [9][KP]: the taps, tap-major
   if ((N & 15) || (K & 15)) {
     for (int idx = tid; idx < MT * KC * 256; idx += 256) wfrag[idx] = 0.f;
     __syncthreads();
@@ -62,7 +132,6 @@ __global__ __launch_bounds__(256) void pw_virt_fwd_kernel(LazySrc In, const floa
     cf[3 * KP + k] = (in && Dw.coef) ? Dw.coef[K + k] : 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) wt[t * KP + k] = in ? wdw[(size_t)k * 9 + t] : 0.f;    // depthwise weight (C, 1, 3, 3)
-    wt[9 * KP + k] = 0.f;
   }
   __syncthreads();
 
@@ -71,75 +140,113 @@ __global__ __launch_bounds__(256) void pw_virt_fwd_kernel(LazySrc In, const floa
   for (int m = 0; m < MT; ++m) s1[m] = s2[m] = f4(0.f);
   const float ilo = In.relu6 ? 0.f : -INFINITY, ihi = In.relu6 ? 6.f : INFINITY;
   const float dlo = Dw.relu6 ? 0.f : -INFINITY, dhi = Dw.relu6 ? 6.f : INFINITY;
-  const long ntiles = (d.npix + 15) >> 4;
-  const unsigned per_img = (unsigned)d.Ho * (unsigned)d.Wo;
+  const CellTiles ct(d);
+  const long iters = (ct.ntiles + gridDim.x - 1) / gridDim.x;
 
-  // raw source cells of the NEXT tile are requested before the MFMAs of the current one (clamped, always valid
-  // addresses; an absent source repeats cell (m, x) and meets a zero tap)
-  float4 r[KC][4];
-  int npy = 0, npx = 0;
-  auto issue = [&](long tile) {
-    long pix = tile * 16 + p;
-    pix = pix < d.npix ? pix : d.npix - 1;
-    const unsigned b = (unsigned)pix / per_img, rem = (unsigned)pix - b * per_img;
-    const unsigned oy = rem / (unsigned)d.Wo, ox = rem - oy * (unsigned)d.Wo;
-    npy = oy & 1;
-    npx = ox & 1;
-    const size_t cell = (((size_t)b * d.Hi + (oy >> 1)) * d.Wi + (ox >> 1)) * K;
-    const size_t o1 = npx ? (size_t)K : 0, o2 = npy ? (size_t)d.Wi * K : 0;
+  // Source cells of a parity class in the order the stand-alone kernel sums them, with their taps:
+  //   (0,0): (m,x) w4      (0,1): (m,x) w5, (m,x+1) w3      (1,0): (m,x) w7, (m+1,x) w1
+  //   (1,1): (m,x) w8, (m,x+1) w6, (m+1,x) w2, (m+1,x+1) w0
+  float4 r[KCH][4];
+  const float* nsrc = In.y;      // this lane's cell of the requested chunk
+  size_t no1 = 0, no2 = 0;       // offsets of the column / row neighbour (0 where the neighbour is not needed)
+  auto request = [&](const TilePos& t, int par, int h) {
+    int b, m, x;
+    ct.cell(t, p, b, m, x);
+    const int py = par >> 1, px = par & 1;
+    nsrc = In.y + (((size_t)b * d.Hi + m) * d.Wi + x) * K;
+    no1 = (px && x + 1 < d.Wi) ? (size_t)K : 0;
+    no2 = (py && m + 1 < d.Hi) ? (size_t)d.Wi * K : 0;
+    const int ns = (1 + py) * (1 + px);
 #pragma unroll
-    for (int jj = 0; jj < KC; ++jj) {
-      const int ci = 16 * jj + 4 * q;
-      const float* src = In.y + cell + (ci < K ? ci : 0);
-      r[jj][0] = ld4(src);
-      r[jj][1] = ld4(src + o1);
-      r[jj][2] = ld4(src + o2);
-      r[jj][3] = ld4(src + o1 + o2);
+    for (int jj = 0; jj < KCH; ++jj) {
+      const int ci = 16 * (h * KCH + jj) + 4 * q;
+      r[jj][0] = ld4(nsrc + (ci < K ? ci : 0));
+    }
+    if (ns > 1) {
+      const size_t o = px ? no1 : no2;
+#pragma unroll
+      for (int jj = 0; jj < KCH; ++jj) {
+        const int ci = 16 * (h * KCH + jj) + 4 * q;
+        r[jj][1] = ld4(nsrc + o + (ci < K ? ci : 0));
+      }
+    }
+    if (ns > 2) {
+#pragma unroll
+      for (int jj = 0; jj < KCH; ++jj) {
+        const int ci = 16 * (h * KCH + jj) + 4 * q;
+        r[jj][2] = ld4(nsrc + no2 + (ci < K ? ci : 0));
+        r[jj][3] = ld4(nsrc + no1 + no2 + (ci < K ? ci : 0));
+      }
     }
   };
-  const long tile0 = (long)blockIdx.x * 4 + wave, tstep = (long)gridDim.x * 4;
-  if (tile0 < ntiles) issue(tile0);
-  for (long tile = tile0; tile < ntiles; tile += tstep) {
-    const long pix = tile * 16 + p;
-    const bool valid = pix < d.npix;
-    const int py = npy, px = npx;
-    int tap[4];
+  auto build = [&](auto ns_tag, int par, int h, float4(&in)[KCH]) {
+    constexpr int NS = decltype(ns_tag)::value;
+    const int py = par >> 1, px = par & 1;
+    const int t0 = (py ? (px ? 8 : 7) : (px ? 5 : 4)) * KP, t1 = (NS == 4 ? 6 : (px ? 3 : 1)) * KP;
 #pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) {
-      const int t = virt_tap(py, px, sidx);
-      tap[sidx] = (t < 0 ? 9 : t) * KP;
-    }
-    float4 in[KC];
-#pragma unroll
-    for (int jj = 0; jj < KC; ++jj) {
-      const int ci = 16 * jj + 4 * q;
+    for (int jj = 0; jj < KCH; ++jj) {
+      const int ci = 16 * (h * KCH + jj) + 4 * q;
       const float4 sc = ld4(cf + ci), sh = ld4(cf + KP + ci);
-      float4 y = clamp4(fma4(r[jj][0], sc, sh), ilo, ihi) * ld4(wt + tap[0] + ci);
-      y = fma4(clamp4(fma4(r[jj][1], sc, sh), ilo, ihi), ld4(wt + tap[1] + ci), y);
-      y = fma4(clamp4(fma4(r[jj][2], sc, sh), ilo, ihi), ld4(wt + tap[2] + ci), y);
-      y = fma4(clamp4(fma4(r[jj][3], sc, sh), ilo, ihi), ld4(wt + tap[3] + ci), y);
-      const float4 v = clamp4(fma4(y, ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci)), dlo, dhi);
-      const bool okc = valid && ci < K;
-      in[jj] = make_float4(okc ? v.x : 0.f, okc ? v.y : 0.f, okc ? v.z : 0.f, okc ? v.w : 0.f);
-    }
-    issue(tile + tstep < ntiles ? tile + tstep : tile);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int jj = 0; jj < KC; ++jj) {
-        const float4 wa = ld4(wfrag + ((m * KC + jj) * 64 + lane) * 4);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, acc, 0, 0, 0);
+      float4 y = clamp4(fma4(r[jj][0], sc, sh), ilo, ihi) * ld4(wt + t0 + ci);
+      if (NS > 1) y = fma4(clamp4(fma4(r[jj][1], sc, sh), ilo, ihi), ld4(wt + t1 + ci), y);
+      if (NS > 2) {
+        y = fma4(clamp4(fma4(r[jj][2], sc, sh), ilo, ihi), ld4(wt + 2 * KP + ci), y);
+        y = fma4(clamp4(fma4(r[jj][3], sc, sh), ilo, ihi), ld4(wt + ci), y);
       }
-      const int co = 16 * m + 4 * q;
-      const float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      in[jj] = clamp4(fma4(y, ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci)), dlo, dhi);
+    }
+  };
+
+  TilePos cur = ct.pos(blockIdx.x), nxt = cur;
+  request(cur, wave & 3, 0);
+  for (long it = 0; it < iters; ++it) {
+    const int par = (wave + (int)it) & 3, py = par >> 1, px = par & 1;
+    int b, m, x;
+    const bool ex = ct.cell(cur, p, b, m, x);
+    const bool valid = ex && (!py || m + 1 < d.Hi) && (!px || x + 1 < d.Wi);
+    const size_t pix = ((size_t)b * d.Ho + 2 * m + py) * d.Wo + 2 * x + px;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      float4 in[KCH];
+      if (par == 0) build(std::integral_constant<int, 1>{}, par, h, in);
+      else if (par == 3) build(std::integral_constant<int, 4>{}, par, h, in);
+      else build(std::integral_constant<int, 2>{}, par, h, in);
+      if (h + 1 < KH) {
+        request(cur, par, h + 1);
+      } else {
+        ct.advance(nxt);
+        request(nxt, (wave + (int)it + 1) & 3, 0);
+      }
+#pragma unroll
+      for (int jj = 0; jj < KCH; ++jj) {
+        const int ci = 16 * (h * KCH + jj) + 4 * q;
+        const bool okc = valid && ci < K;
+        in[jj] = make_float4(okc ? in[jj].x : 0.f, okc ? in[jj].y : 0.f, okc ? in[jj].z : 0.f, okc ? in[jj].w : 0.f);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int jj = 0; jj < KCH; ++jj) {
+          const float4 wa = ld4(wfrag + ((mt * KC + h * KCH + jj) * 64 + lane) * 4);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+    cur = nxt;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = 16 * mt + 4 * q;
+      const float4 o = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
       if (valid && co < N) {
-        st4(out + (size_t)pix * N + co, o);
-        s1[m] = s1[m] + o;
-        s2[m] = fma4(o, o, s2[m]);
+        st4(out + pix * N + co, o);
+        s1[mt] = s1[mt] + o;
+        s2[mt] = fma4(o, o, s2[mt]);
       }
     }
   }
@@ -166,22 +273,306 @@ __global__ __launch_bounds__(256) void pw_virt_fwd_kernel(LazySrc In, const floa
     __syncthreads();
     for (int i = tid; i < 2 * N; i += 256) {
       const int j = i / N, c = i - j * N;
-      float s = 0.f;
+      float sum = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) s += red[(wv * 2 + j) * MT * 16 + c];
-      slab[(size_t)blockIdx.x * 2 * N + i] = s;
+      for (int wv = 0; wv < 4; ++wv) sum += red[(wv * 2 + j) * MT * 16 + c];
+      slab[(size_t)blockIdx.x * 2 * N + i] = sum;
     }
   }
 }
 
-template <int KC, int MT>
+template <int KCH, int KH, int MT>
 int launch_virt(LazySrc In, const float* wdw, LazySrc Dw, const float* W, float* out, float* slab, VirtDims d, int& grid,
                 hipStream_t st) {
-  const size_t smem = (size_t)(MT * KC * 256 + 14 * KC * 16) * sizeof(float);
-  auto kfn = pw_virt_fwd_kernel<KC, MT>;
+  constexpr int KC = KCH * KH;
+  const size_t smem = (size_t)(MT * KC * 256 + 13 * KC * 16) * sizeof(float);
+  auto kfn = pw_virt_fwd_kernel<KCH, KH, MT>;
   NOISE_ALLOW_LDS(kfn, smem);
   grid = noise_whole_rounds(grid, kfn, 256, smem);
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), smem, st, In, wdw, Dw, W, out, slab, d);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the same projection (fused input gradient + weight gradient + the depthwise BatchNorm's backward sums,
+// see pw_bwd_kernel in pw.hip), again without the depthwise output in memory.  A tile is 16 consecutive source cells
+// (b, m, x) = 64 output pixels (2m + py, 2x + px): wave w owns parity class (py, px) = (w >> 1, w & 1), so one source
+// window (m..m+1, x..x+1) serves four output pixels.  Per tile:
+//   1. dy of the 64 pixels (lazy BatchNorm backward of the projection's own BatchNorm) -> LDS;
+//      the raw depthwise output and its activation, rebuilt from the source window -> LDS (two tiles);
+//   2. input gradient g = dy W per wave (MFMA), ReLU6 mask and the producer's sums from the raw tile, store;
+//      weight gradient dW += dy^T a over the 64 pixels from the activated tile.
+// The next tile's global loads are requested right after the staging barrier and stay in registers through the MFMAs.
+constexpr int virt_bwd_pitch(int tiles) { return tiles * 16 + 4; }
+constexpr int virt_bwd_lds_floats(int KC, int MTI) {
+  return MTI * KC * 256 + 64 * virt_bwd_pitch(KC) + 2 * 64 * virt_bwd_pitch(MTI) + 17 * MTI * 16;
+}
+constexpr int virt_bwd_min_blocks(int KC, int MTI) { return virt_bwd_lds_floats(KC, MTI) * 8 <= 160 * 1024 ? 2 : 1; }
+
+template <int KC, int MTI>
+__global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd_kernel(
+    LazyGrad G, LazySrc In, const float* __restrict__ wdw, const float* __restrict__ dwcoef, int dw_relu6,
+    const float* __restrict__ W, float* __restrict__ g_in, float* __restrict__ stats_slab, float* __restrict__ dw_slab,
+    VirtDims d) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int K = d.K, N = d.N;
+  constexpr int NP = KC * 16, KP = MTI * 16;
+  constexpr int pn = virt_bwd_pitch(KC), pk = virt_bwd_pitch(MTI);
+  float* wfrag = lds;                       // [MTI][KC][64][4] fragment image of W for the input gradient
+  float* dys = wfrag + MTI * KC * 256;      // [64][pn] dy, row 16 * parity + cell
+  float* as = dys + 64 * pn;                // [64][pk] activated depthwise output
+  float* raws = as + 64 * pk;               // [64][pk] raw depthwise output
+  float* cf = raws + 64 * pk;               // [7][KP]: source scale, shift; depthwise scale, shift, mean, invstd, mean_lo
+  float* wt = cf + 7 * KP;                  // [10][KP]: the 9 taps, row 9 unused
+  if ((N & 15) || (K & 15)) {
+    for (int idx = tid; idx < MTI * KC * 256; idx += 256) wfrag[idx] = 0.f;
+    __syncthreads();
+  }
+  {
+    const int K4 = K >> 2;
+#pragma unroll 4
+    for (int e = tid; e < N * K4; e += 256) {
+      const int co = e / K4, ci = 4 * (e - co * K4);
+      const float4 v = ld4(W + (size_t)co * K + ci);
+      float* dst = wfrag + ((((ci >> 4) * KC + (co >> 4)) * 64) + (ci & 15) + 16 * ((co & 15) >> 2)) * 4 + (co & 3);
+      dst[0] = v.x;
+      dst[4] = v.y;
+      dst[8] = v.z;
+      dst[12] = v.w;
+    }
+  }
+  for (int k = tid; k < KP; k += 256) {
+    const bool in = k < K;
+    cf[k] = (in && In.coef) ? In.coef[k] : 1.f;
+    cf[KP + k] = (in && In.coef) ? In.coef[K + k] : 0.f;
+    cf[2 * KP + k] = in ? dwcoef[k] : 1.f;
+    cf[3 * KP + k] = in ? dwcoef[K + k] : 0.f;
+    cf[4 * KP + k] = in ? dwcoef[2 * K + k] : 0.f;
+    cf[5 * KP + k] = in ? dwcoef[3 * K + k] : 1.f;
+    cf[6 * KP + k] = in ? dwcoef[4 * K + k] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t * KP + k] = in ? wdw[(size_t)k * 9 + t] : 0.f;
+  }
+
+  constexpr int T = KC * MTI, TPW = (T + 3) / 4;
+  f32x4 acc[TPW];
+  int dyo[TPW], avo[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t = wave + 4 * j < T ? wave + 4 * j : wave % T, m = t / MTI, n = t - m * MTI;
+    dyo[j] = 16 * m + p;
+    avo[j] = 16 * n + p;
+  }
+  float4 s1[MTI], s2[MTI];
+#pragma unroll
+  for (int m = 0; m < MTI; ++m) s1[m] = s2[m] = f4(0.f);
+
+  // dy staging map: channel group fastest, then the cell, then the parity class (KC classes per pass)
+  constexpr int CGN = NP / 4, JP = 16 / CGN, PASS_N = 4 / JP;
+  const int cn = (tid % CGN) * 4, in_cell = (tid / CGN) & 15, jn0 = tid / (CGN * 16);
+  const bool on = cn < N;
+  float4 gs = f4(1.f), gk1h = f4(0.f), gk1l = f4(0.f), ga2 = f4(0.f), gmh = f4(0.f), gml = f4(0.f);
+  if (on && G.coef3) {
+    gs = ld4(G.coef3 + cn);
+    gk1h = ld4(G.coef3 + N + cn);
+    gk1l = ld4(G.coef3 + 2 * N + cn);
+    ga2 = ld4(G.coef3 + 3 * N + cn);
+    gmh = ld4(G.coef3 + 4 * N + cn);
+    gml = ld4(G.coef3 + 5 * N + cn);
+  }
+  // source staging map: item = (cell, channel group), channel group fastest
+  constexpr int CGK = KP / 4, ITEMS = 16 * CGK, PASS_V = (ITEMS + 255) / 256;
+  const float ilo = In.relu6 ? 0.f : -INFINITY, ihi = In.relu6 ? 6.f : INFINITY;
+  const float dlo = dw_relu6 ? 0.f : -INFINITY, dhi = dw_relu6 ? 6.f : INFINITY;
+
+  const long ntiles = (d.ncells + 15) >> 4;
+  const long iters = (ntiles + gridDim.x - 1) / gridDim.x;
+  const CellTiles ct(d);
+
+  float4 rz[PASS_N], ry[PASS_N], r[PASS_V][4];
+  int nflag = 0;
+  auto issue_tile = [&](const TilePos& tile) {
+    {
+      int b, m, x;
+      const bool ex = ct.cell(tile, in_cell, b, m, x);
+      const bool vy1 = m + 1 < d.Hi, vx1 = x + 1 < d.Wi;
+      nflag = 0;
+#pragma unroll
+      for (int u = 0; u < PASS_N; ++u) {
+        const int j = jn0 + JP * u, py = j >> 1, px = j & 1;
+        const bool ok = ex && (!py || vy1) && (!px || vx1);
+        const int oy = 2 * m + ((py && vy1) ? 1 : 0), ox = 2 * x + ((px && vx1) ? 1 : 0);
+        const size_t off = (((size_t)b * d.Ho + oy) * d.Wo + ox) * N + (on ? cn : 0);
+        rz[u] = ld4(G.dz + off);
+        ry[u] = G.coef3 ? ld4(G.y + off) : f4(0.f);
+        nflag |= ok ? (1 << u) : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PASS_V; ++u) {
+      const int idx = tid + 256 * u;
+      const int ci = idx < ITEMS ? idx / CGK : 15, cg = idx < ITEMS ? idx - ci * CGK : 0;
+      int b, m, x;
+      ct.cell(tile, ci, b, m, x);
+      const bool vy1 = m + 1 < d.Hi, vx1 = x + 1 < d.Wi;
+      const int ck = 4 * cg;
+      const float* src = In.y + (((size_t)b * d.Hi + m) * d.Wi + x) * K + (ck < K ? ck : 0);
+      const size_t o1 = vx1 ? (size_t)K : 0, o2 = vy1 ? (size_t)d.Wi * K : 0;
+      r[u][0] = ld4(src);
+      r[u][1] = ld4(src + o1);
+      r[u][2] = ld4(src + o2);
+      r[u][3] = ld4(src + o1 + o2);
+    }
+  };
+  TilePos cur = ct.pos(blockIdx.x), nxt = cur;
+  issue_tile(cur);
+  for (long it = 0; it < iters; ++it) {
+    __syncthreads();   // the previous tile's MFMAs have read the staged tiles (first pass: the tables are written)
+#pragma unroll
+    for (int u = 0; u < PASS_N; ++u) {
+      const int pp = 16 * (jn0 + JP * u) + in_cell;
+      float4 v = rz[u];
+      if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
+      st4(dys + pp * pn + cn, (on && ((nflag >> u) & 1)) ? v : f4(0.f));
+    }
+#pragma unroll
+    for (int u = 0; u < PASS_V; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < ITEMS) {
+        const int ci = idx / CGK, ck = 4 * (idx - ci * CGK);
+        const float4 sc = ld4(cf + ck), sh = ld4(cf + KP + ck);
+        const float4 s00 = clamp4(fma4(r[u][0], sc, sh), ilo, ihi), s01 = clamp4(fma4(r[u][1], sc, sh), ilo, ihi);
+        const float4 s10 = clamp4(fma4(r[u][2], sc, sh), ilo, ihi), s11 = clamp4(fma4(r[u][3], sc, sh), ilo, ihi);
+        float4 y[4];
+        y[0] = s00 * ld4(wt + 4 * KP + ck);
+        y[1] = fma4(s01, ld4(wt + 3 * KP + ck), s00 * ld4(wt + 5 * KP + ck));
+        y[2] = fma4(s10, ld4(wt + 1 * KP + ck), s00 * ld4(wt + 7 * KP + ck));
+        y[3] = s00 * ld4(wt + 8 * KP + ck);
+        y[3] = fma4(s01, ld4(wt + 6 * KP + ck), y[3]);
+        y[3] = fma4(s10, ld4(wt + 2 * KP + ck), y[3]);
+        y[3] = fma4(s11, ld4(wt + ck), y[3]);
+        const float4 dsc = ld4(cf + 2 * KP + ck), dsh = ld4(cf + 3 * KP + ck);
+        // rows of pixels that do not exist keep whatever the clamped loads gave (finite): their dy rows are zero, so
+        // the weight gradient ignores them, and the input-gradient epilogue skips them
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st4(raws + (16 * j + ci) * pk + ck, y[j]);
+          st4(as + (16 * j + ci) * pk + ck, clamp4(fma4(y[j], dsc, dsh), dlo, dhi));
+        }
+      }
+    }
+    __syncthreads();
+    ct.advance(nxt);
+    issue_tile(nxt);
+    // ---- input gradient of this wave's parity class
+    {
+      int b, m, x;
+      const bool ex = ct.cell(cur, p, b, m, x);
+      cur = nxt;
+      const int py = wave >> 1, px = wave & 1;
+      const bool valid = ex && (!py || m + 1 < d.Hi) && (!px || x + 1 < d.Wi);
+      const size_t prow = (((size_t)b * d.Ho + 2 * m + py) * d.Wo + 2 * x + px) * K;
+      float4 in[KC];
+#pragma unroll
+      for (int jj = 0; jj < KC; ++jj) in[jj] = ld4(dys + (16 * wave + p) * pn + 16 * jj + 4 * q);
+#pragma unroll
+      for (int m2 = 0; m2 < MTI; ++m2) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) {
+          const float4 wa = ld4(wfrag + ((m2 * KC + jj) * 64 + lane) * 4);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, o, 0, 0, 0);
+        }
+        const int ci = 16 * m2 + 4 * q;
+        if (valid && ci < K) {
+          float4 g = make_float4(o[0], o[1], o[2], o[3]);
+          const float4 yraw = ld4(raws + (16 * wave + p) * pk + ci);
+          if (dw_relu6) {   // the clamped activation is strictly inside (0, 6) exactly where the ReLU6 passes gradient
+            const float4 v = ld4(as + (16 * wave + p) * pk + ci);
+            g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
+            g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
+            g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
+            g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
+          }
+          const float4 xh = sub4(sub4(yraw, ld4(cf + 4 * KP + ci)), ld4(cf + 6 * KP + ci)) * ld4(cf + 5 * KP + ci);
+          s1[m2] = s1[m2] + g;
+          s2[m2] = fma4(g, xh, s2[m2]);
+          st4(g_in + prow + ci, g);
+        }
+      }
+    }
+    // ---- weight gradient: 16 k-steps of 4 pixels over this wave's tiles of dW
+#pragma unroll 2
+    for (int s = 0; s < 16; ++s) {
+      const int pp = 4 * s + q;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
+    }
+  }
+
+  // ---- the depthwise BatchNorm's backward sums: reduce over the 16 pixel lanes, then over the waves
+  __syncthreads();
+  {
+    float* red = lds;   // [4 waves][2][KP]
+#pragma unroll
+    for (int m = 0; m < MTI; ++m) {
+      float v[8] = {s1[m].x, s1[m].y, s1[m].z, s1[m].w, s2[m].x, s2[m].y, s2[m].z, s2[m].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v[e] += __shfl_xor(v[e], o, 64);
+      }
+      if (p == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[(wave * 2 + 0) * KP + 16 * m + 4 * q + e] = v[e];
+          red[(wave * 2 + 1) * KP + 16 * m + 4 * q + e] = v[4 + e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i2 = tid; i2 < 2 * K; i2 += 256) {
+      const int j = i2 / K, c = i2 - j * K;
+      float sum = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) sum += red[(wv * 2 + j) * KP + c];
+      stats_slab[(size_t)blockIdx.x * 2 * K + i2] = sum;
+    }
+    __syncthreads();
+  }
+  // ---- dW: every tile has one owning wave; the block writes its slab row with coalesced stores
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = wave + 4 * j;
+    if (t < T) {
+      const int m = t / MTI, n = t - m * MTI;
+      const int ci = 16 * n + p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = 16 * m + 4 * q + e;
+        if (co < N && ci < K) lds[co * K + ci] = acc[j][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < N * K; j += 256) dw_slab[(size_t)blockIdx.x * N * K + j] = lds[j];
+}
+
+template <int KC, int MTI>
+int launch_virt_bwd(LazyGrad G, LazySrc In, const float* wdw, const float* dwcoef, int dw_relu6, const float* W,
+                    float* g_in, float* stats_slab, float* dw_slab, VirtDims d, int& grid, hipStream_t st) {
+  const size_t smem = (size_t)virt_bwd_lds_floats(KC, MTI) * sizeof(float);
+  auto kfn = pw_virt_bwd_kernel<KC, MTI>;
+  NOISE_ALLOW_LDS(kfn, smem);
+  grid = noise_whole_rounds(grid, kfn, 256, smem);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), smem, st, G, In, wdw, dwcoef, dw_relu6, W, g_in, stats_slab, dw_slab, d);
   return 0;
 }
 
@@ -205,15 +596,46 @@ NOISE_EXPORT int noise_pw_fwd_virt(const float* in_y, const float* in_coef, int 
   const int Ho = 2 * Hi - 1, Wo = 2 * Wi - 1;
   const long npix = (long)B * Ho * Wo;
   NOISE_REQUIRE(npix < (1L << 31) && (long)B * Hi * Wi * K < (1L << 40), "noise_pw_fwd_virt: tensor too large");
-  VirtDims d{npix, K, N, Hi, Wi, Ho, Wo};
+  VirtDims d{npix, K, N, Hi, Wi, Ho, Wo, (long)B * Hi * Wi};
   LazySrc In{in_y, in_coef, in_relu6}, Dw{nullptr, dw_coef, dw_relu6};
-  int grid = noise_grid(npix, 16 * 4 * 4, 1024);
+  int grid = noise_grid((long)B * Hi * Wi, 16, 1024);
   const int KC = (K + 15) / 16, MT = (N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  if (KC == 5 && MT == 1) launch_virt<5, 1>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
-  else if (KC == 6 && MT == 2) launch_virt<6, 2>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
-  else launch_virt<12, 2>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
+  if (KC == 5 && MT == 1) launch_virt<5, 1, 1>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
+  else if (KC == 6 && MT == 2) launch_virt<6, 1, 2>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
+  else launch_virt<6, 2, 2>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
   if (slab_rows) *slab_rows = grid;
   NOISE_CHECK_LAUNCH("noise_pw_fwd_virt");
+  return 0;
+}
+
+// Backward of noise_pw_fwd_virt: g_in (B, 2Hi-1, 2Wi-1, K) = dL/d(activated depthwise output), masked by the depthwise
+// ReLU6, with the depthwise BatchNorm's backward sums [sum g | sum g*xhat] in stats_slab (*slab_rows rows of 2K floats),
+// and the per-workgroup weight-gradient rows (N*K floats each) in scratch.  dz / y_out / coef3: lazy gradient of the
+// projection's output (coef3 NULL: dz is dL/dy).  dw_coef: [scale | shift | mean | invstd | mean_lo] of the depthwise
+// BatchNorm.  scratch and stats_slab: noise_pw_bwd_max_rows(N, K) rows.
+NOISE_EXPORT int noise_pw_bwd_virt(const float* dz, const float* y_out, const float* coef3, const float* in_y,
+                                   const float* in_coef, int in_relu6, const float* wdw, const float* dw_coef,
+                                   int dw_relu6, const float* w, float* g_in, float* scratch, float* stats_slab,
+                                   int* slab_rows, int B, int Hi, int Wi, int K, int N, void* stream) {
+  NOISE_REQUIRE(dz && in_y && wdw && dw_coef && w && g_in && scratch && stats_slab, "noise_pw_bwd_virt: null pointer");
+  NOISE_REQUIRE(coef3 == nullptr || y_out != nullptr, "noise_pw_bwd_virt: coef3 needs y_out");
+  NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "noise_pw_bwd_virt: empty input");
+  NOISE_REQUIRE(K % 8 == 0 && N % 4 == 0 && noise_pw_fwd_virt_supported(K, N),
+                "noise_pw_bwd_virt: no kernel instance for K=%d N=%d (served: 72->16, 96->24, 192->32)", K, N);
+  const int Ho = 2 * Hi - 1, Wo = 2 * Wi - 1;
+  const long npix = (long)B * Ho * Wo, ncells = (long)B * Hi * Wi;
+  NOISE_REQUIRE(npix < (1L << 31) && ncells * K < (1L << 40), "noise_pw_bwd_virt: tensor too large");
+  VirtDims d{npix, K, N, Hi, Wi, Ho, Wo, ncells};
+  LazyGrad G{dz, y_out, coef3};
+  LazySrc In{in_y, in_coef, in_relu6};
+  int grid = noise_grid(ncells, 16, noise_pw_bwd_max_rows(N, K));
+  const int KC = (N + 15) / 16, MTI = (K + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (KC == 1 && MTI == 5) launch_virt_bwd<1, 5>(G, In, wdw, dw_coef, dw_relu6, w, g_in, stats_slab, scratch, d, grid, st);
+  else if (KC == 2 && MTI == 6) launch_virt_bwd<2, 6>(G, In, wdw, dw_coef, dw_relu6, w, g_in, stats_slab, scratch, d, grid, st);
+  else launch_virt_bwd<2, 12>(G, In, wdw, dw_coef, dw_relu6, w, g_in, stats_slab, scratch, d, grid, st);
+  if (slab_rows) *slab_rows = grid;
+  NOISE_CHECK_LAUNCH("noise_pw_bwd_virt");
   return 0;
 }

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void walk_gather_fwd_kernel(LazySrc A, LazySrc
   }
 }
 
-// forward, cell geometry (transposed convolution, stride 2)
-template <bool HAS_B>
+// forward, cell geometry (transposed convolution, stride 2).  STORE = false: statistics only -- the output is left to
+// consumers that rebuild it from the layer input (pwvirt.hip), `out` is not dereferenced.
+template <bool HAS_B, bool STORE = true>
 __global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc Bsrc, const float* __restrict__ w,
                                                             float* __restrict__ out, float* __restrict__ slab,
                                                             WalkDims d) {
@@ -171,18 +172,18 @@ __global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc B
       for (int m = m0; m < m1; ++m, o += 2 * drow) {
         load_row(m + 1, s10, s11);
         const float4 d00 = s00 * wk[4];
-        st4(o, d00);
+        if (STORE) st4(o, d00);
         s1 = s1 + d00;
         s2 = fma4(d00, d00, s2);
         if (dx1) {
           const float4 d01 = fma4(s01, wk[3], s00 * wk[5]);
-          st4(o + C, d01);
+          if (STORE) st4(o + C, d01);
           s1 = s1 + d01;
           s2 = fma4(d01, d01, s2);
         }
         if (2 * m + 1 < d.Hd) {
           const float4 d10 = fma4(s10, wk[1], s00 * wk[7]);
-          st4(o + drow, d10);
+          if (STORE) st4(o + drow, d10);
           s1 = s1 + d10;
           s2 = fma4(d10, d10, s2);
           if (dx1) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void walk_cell_fwd_kernel(LazySrc A, LazySrc B
             d11 = fma4(s01, wk[6], d11);
             d11 = fma4(s10, wk[2], d11);
             d11 = fma4(s11, wk[0], d11);
-            st4(o + drow + C, d11);
+            if (STORE) st4(o + drow + C, d11);
             s1 = s1 + d11;
             s2 = fma4(d11, d11, s2);
           }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
         r[2] = keep4(vy && v2, x2);
       };
       float4 t0[3], t1[3], t2[3];
-      load_row(r0 * S - 1, t0);
+      if (!RECOMP) load_row(r0 * S - 1, t0);
       if (S == 1) load_row(r0, t1);
       size_t ioff = (((size_t)bi * d.Hd + r0) * d.Wd + ox) * C + c;
       const size_t drow = (size_t)d.Wd * C;
@@ -319,6 +320,29 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
         a0[0] = keep4(vxm, a0[0]);
         a0[2] = keep4(vxp, a0[2]);
         ymid = q1;
+        // source row 2*r0 - 1 above a band that does not start at the top: its y comes from input rows r0 - 1 and r0
+        // like every other row's (the layer's output is never read, so it need not exist in memory)
+        const bool vp = r0 > 0;
+        const size_t prow = ((size_t)bi * d.Hd + (vp ? r0 - 1 : r0)) * d.Wd * C + c;
+        float4 ap[3];
+        ap[0] = lazy4_at(px.a, prow + nxm);
+        ap[1] = lazy4_at(px.a, prow + nx);
+        ap[2] = lazy4_at(px.a, prow + nxp);
+        if (HAS_B) {
+          ap[0] = ap[0] + lazy4_at(px.b, prow + nxm);
+          ap[1] = ap[1] + lazy4_at(px.b, prow + nx);
+          ap[2] = ap[2] + lazy4_at(px.b, prow + nxp);
+        }
+        ap[0] = keep4(vxm, ap[0]);
+        ap[2] = keep4(vxp, ap[2]);
+        float4 yb[3];
+        yb[0] = fma4(a0[1], wk[0], fma4(a0[0], wk[2], fma4(ap[1], wk[6], ap[0] * wk[8])));
+        yb[1] = fma4(a0[1], wk[1], ap[1] * wk[7]);
+        yb[2] = fma4(a0[2], wk[0], fma4(a0[1], wk[2], fma4(ap[2], wk[6], ap[1] * wk[8])));
+        const size_t srow = clip + (size_t)(vp ? 2 * r0 - 1 : 0) * d.Ws * C;
+        t0[0] = keep4(vp && v0, lazygrad4_eval(gr, ld4(gr.dz + srow + (size_t)cx0 * C), yb[0]));
+        t0[1] = keep4(vp && v1, lazygrad4_eval(gr, ld4(gr.dz + srow + (size_t)cx1 * C), yb[1]));
+        t0[2] = keep4(vp && v2, lazygrad4_eval(gr, ld4(gr.dz + srow + (size_t)cx2 * C), yb[2]));
       }
       issue(r0, ioff);
 #pragma unroll 1

@@ -45,7 +45,7 @@ ATTN_DROPOUT = 0.1  # ScaledDotProductAttention default, never overridden by the
 class _Rec:
     """One convolution layer of the schedule and the buffers that belong to it."""
     __slots__ = ("name", "kind", "conv", "bn", "relu6", "C", "Cin", "B", "Hi", "Wi", "Ho", "Wo", "stride",
-                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "dz", "g_in", "wslab")
+                 "transposed", "y", "coef", "coef3", "src_a", "src_b", "dz", "g_in", "wslab", "virt")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -181,8 +181,11 @@ class DenoiserPlan:
         self.att_slab_post = torch.empty(ATTN_MAX_BLOCKS * (2 * D * D + D * hd + 7 * D + 1), **f32)
         self.att_slab_pre = torch.empty(ATTN_MAX_BLOCKS * (3 * hd * D + 2 * D), **f32)
         self.bwd_ready = False
-        # eval forwards skip materialising the output of stride-2 transposed depthwise layers (NOISE_VIRTUAL_DW=0: keep it)
-        self.virtual_dw = os.environ.get("NOISE_VIRTUAL_DW", "1") != "0"
+        # the output of the decoder's stride-2 transposed depthwise layers is never materialised (NOISE_VIRTUAL_DW=0: it is)
+        # (a comma-separated list of channel counts restricts it to those layers)
+        v = os.environ.get("NOISE_VIRTUAL_DW", "1")
+        self.virtual_dw = v != "0" and "NOISE_DW_NO_RECOMPUTE" not in os.environ
+        self.virtual_dw_channels = {int(c) for c in v.split(",")} if "," in v or v not in ("0", "1") else None
 
     # -------------------------------------------------------------------------------- backward buffers
     def ensure_backward_buffers(self):
@@ -277,17 +280,23 @@ class DenoiserPlan:
                 if virt is not None:
                     # projection of a transposed block: the depthwise output is rebuilt inside the 1x1 convolution
                     dw, virt = virt, None
-                    r.src_a, r.src_b = dw.lazy(), None
-                    ops.pw_fwd_virt(dw.src_a, dw.conv.weight, dw.coef, dw.relu6, r.conv.weight, r.y, None, dw.B, dw.Hi,
-                                    dw.Wi, r.Cin, r.C)
-                    self._bn(r, 0, training)
+                    r.src_a, r.src_b, r.virt = dw.lazy(), None, dw
+                    rows = ops.pw_fwd_virt(dw.src_a, dw.conv.weight, dw.coef, dw.relu6, r.conv.weight, r.y,
+                                           self.slab if training else None, dw.B, dw.Hi, dw.Wi, r.Cin, r.C)
+                    self._bn(r, rows, training)
                     cur = r.lazy()
                     continue
-                if (self.virtual_dw and not training and not first and r.kind == "dw" and r.transposed
-                        and tuple(r.stride) == (2, 2) and ops.pw_fwd_virt_supported(r.C, layers[-1].C)):
-                    # eval forward: nothing reads the depthwise output but the projection that follows it
+                r.virt = None
+                if (self.virtual_dw and not first and r.kind == "dw" and r.transposed and tuple(r.stride) == (2, 2)
+                        and (self.virtual_dw_channels is None or r.C in self.virtual_dw_channels)
+                        and ops.pw_fwd_virt_supported(r.C, layers[-1].C)):
+                    # nothing reads the depthwise output but the projection behind it (forward and backward) and this
+                    # layer's own backward, which rebuilds it as well: a training forward only takes its statistics
                     r.src_a, r.src_b = cur, None
-                    self._bn(r, 0, training)
+                    rows = 0
+                    if training:
+                        rows = ops.dw3x3_fwd(cur, None, r.conv.weight, None, self.slab, True, r.B, r.Hi, r.Wi, r.C, r.stride)
+                    self._bn(r, rows, training)
                     virt = r
                     continue
                 if r.kind == "last":
@@ -349,8 +358,13 @@ class DenoiserPlan:
             pa, pb = producer(r.src_a), producer(r.src_b)
             g_other, epi = epilogue_for(pa)
             if r.kind == "pw":
-                rows = ops.pw_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, None, r.wslab, r.npix_in,
-                                  r.C, r.Cin, g_other, epi, self.slab2)
+                if r.virt is not None:
+                    dw = r.virt     # == pa: the depthwise layer whose output was never written
+                    rows = ops.pw_bwd_virt(grad, dw.src_a, dw.conv.weight, dw.coef, dw.relu6, r.conv.weight, r.g_in,
+                                           r.wslab, self.slab2, dw.B, dw.Hi, dw.Wi, r.Cin, r.C)
+                else:
+                    rows = ops.pw_bwd(grad, r.src_a, r.src_b, r.conv.weight, r.g_in, None, r.wslab, r.npix_in,
+                                      r.C, r.Cin, g_other, epi, self.slab2)
                 finalize(pa, self.slab2, rows, 2 * r.Cin)
                 fold.append((r.wslab, G(r.conv.weight), rows, r.C * r.Cin, r.C * r.Cin, 0, 0))
             else:

@@ -28,6 +28,7 @@ _lib.register({
     "noise_pw_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
     "noise_pw_fwd_virt_supported": [_I, _I],
     "noise_pw_fwd_virt": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "noise_pw_bwd_virt": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "noise_pw_dgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "noise_pw_wgrad": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_pw_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
@@ -76,11 +77,12 @@ def crop_nhwc(src, dst, oy, ox):
 
 
 def dw3x3_fwd(a, b, w, out, slab, transposed, B, Hi, Wi, C, stride):
-    """Returns the number of slab rows written (0 when slab is None)."""
+    """Returns the number of slab rows written (0 when slab is None).  out None (stride-2 transposed layers only):
+    statistics pass, the output is not written."""
     rows = ctypes.c_int(0)
     _lib.call("noise_dw3x3_fwd", *_src(a), *_src(b), ptr(w), ptr(out), ptr(slab), ctypes.byref(rows),
               int(transposed), B, Hi, Wi, C, stride[0], stride[1], _lib.stream(),
-              nbytes=4 * C * (B * Hi * Wi * _nsrc(b) + out.numel() // C))
+              nbytes=4 * C * (B * Hi * Wi * _nsrc(b) + (out.numel() // C if out is not None else 0)))
     return rows.value
 
 
@@ -171,6 +173,18 @@ def pw_fwd_virt(src, wdw, dw_coef, dw_relu6, w, out, slab, B, Hi, Wi, K, N):
     npix = B * (2 * Hi - 1) * (2 * Wi - 1)
     _lib.call("noise_pw_fwd_virt", *_src(src), ptr(wdw), ptr(dw_coef), int(dw_relu6), ptr(w), ptr(out), ptr(slab),
               ctypes.byref(rows), B, Hi, Wi, K, N, _lib.stream(), nbytes=4 * (B * Hi * Wi * K + npix * N))
+    return rows.value
+
+
+def pw_bwd_virt(grad, src, wdw, dw_coef, dw_relu6, w, g_in, scratch, stats_slab, B, Hi, Wi, K, N):
+    """Backward of pw_fwd_virt: input gradient (B, 2Hi-1, 2Wi-1, K), weight-gradient slab rows in `scratch`, the
+    depthwise BatchNorm's backward sums in `stats_slab`.  Returns the number of rows of both."""
+    dz, y, coef3 = grad
+    rows = ctypes.c_int(0)
+    npix = B * (2 * Hi - 1) * (2 * Wi - 1)
+    _lib.call("noise_pw_bwd_virt", ptr(dz), ptr(y), ptr(coef3), *_src(src), ptr(wdw), ptr(dw_coef), int(dw_relu6),
+              ptr(w), ptr(g_in), ptr(scratch), ptr(stats_slab), ctypes.byref(rows), B, Hi, Wi, K, N, _lib.stream(),
+              nbytes=4 * (npix * (N * (2 if coef3 is not None else 1) + K) + B * Hi * Wi * K))
     return rows.value
 
 

@@ -122,6 +122,16 @@ def test_depthwise(dev, C, stride, transposed, two_src, shape):
                   transposed, B, Hi, Wi, C, stride)
     close(nchw(g_in), a_in.grad, msg="dgrad")
     close(dw, w.grad, 1e-4, "wgrad")
+    if transposed and tuple(stride) == (2, 2):
+        # these layers rebuild their raw output from the input: the output tensor need not exist (virtual tensors), and
+        # the statistics-only forward pass leaves the same sums without writing it
+        g2, dw2 = torch.empty_like(g_in), torch.empty_like(dw)
+        ops.dw3x3_bwd((nhwc(dz).to(dev), torch.full_like(out, float("nan")), c3.to(dev)), a_src, b_src, w.detach().to(dev),
+                      g2, dw2, scratch, transposed, B, Hi, Wi, C, stride)
+        assert torch.equal(g2, g_in) and torch.equal(dw2, dw)
+        slab2 = torch.zeros_like(slab)
+        rows2 = ops.dw3x3_fwd(a_src, b_src, w.detach().to(dev), None, slab2, transposed, B, Hi, Wi, C, stride)
+        assert rows2 == rows and torch.equal(slab2[: rows * 2 * C], slab[: rows * 2 * C])
     # fused epilogue: + second gradient, producer ReLU6 mask, producer BatchNorm-backward sums
     other = torch.randn(B, C, Hi, Wi, generator=g)
     relu_a = not two_src
@@ -161,6 +171,48 @@ def test_pointwise_virtual_source(dev, K, N, shape):
     close(a2, b2, 1e-5, "sumsq")
     with pytest.raises(RuntimeError):
         ops.pw_fwd_virt((y_in, c_in, True), wdw, c_dw, True, w, out, slab, B, Hi, Wi, 48, N)
+
+
+@pytest.mark.parametrize("K,N,shape", [(72, 16, (2, 41, 17)), (96, 24, (3, 6, 4)), (192, 32, (2, 11, 5)), (72, 16, (1, 1, 1)),
+                                       (72, 16, (5, 7, 1)), (96, 24, (2, 1, 9)), (192, 32, (3, 21, 9))])
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_pointwise_virtual_source_backward(dev, K, N, shape, with_bn):
+    """Backward of the projection with a rebuilt depthwise output equals noise_pw_bwd on the materialised tensor: input
+    gradient bit for bit (same MFMA order), weight gradient and the depthwise BatchNorm's sums to rounding."""
+    from noise_amd import ops
+    g = torch.Generator().manual_seed(7 * K + shape[1])
+    B, Hi, Wi = shape
+    y_in = nhwc(torch.randn(B, K, Hi, Wi, generator=g)).to(dev)
+    c_in = rand_coef(K, g).to(dev)
+    c_dw = rand_coef(K, g).to(dev)
+    wdw = (torch.randn(K, 1, 3, 3, generator=g) * 0.4).to(dev)
+    w = (torch.randn(N, K, 1, 1, generator=g) * 0.2).to(dev)
+    Ho, Wo = 2 * Hi - 1, 2 * Wi - 1
+    npix = B * Ho * Wo
+    y_dw = torch.empty(B, Ho, Wo, K, device=dev)
+    ops.dw3x3_fwd((y_in, c_in, True), None, wdw, y_dw, None, True, B, Hi, Wi, K, (2, 2))
+    dz = nhwc(torch.randn(B, N, Ho, Wo, generator=g)).to(dev)
+    y_out = nhwc(torch.randn(B, N, Ho, Wo, generator=g)).to(dev)
+    gc = rand_gcoef(N, g).to(dev) if with_bn else None
+    grad = (dz, y_out if with_bn else None, gc)
+    rows_max = ops.pw_bwd_max_rows(N, K)
+    g_ref = torch.empty(B, Ho, Wo, K, device=dev)
+    scr_ref = torch.zeros(rows_max * N * K, device=dev)
+    st_ref = torch.zeros(rows_max * 2 * K, device=dev)
+    rows_r = ops.pw_bwd(grad, (y_dw, c_dw, True), None, w, g_ref, None, scr_ref, npix, N, K, None, (c_dw, True), st_ref)
+    g_in = torch.full((B, Ho, Wo, K), float("nan"), device=dev)
+    scr = torch.zeros(rows_max * N * K, device=dev)
+    st = torch.zeros(rows_max * 2 * K, device=dev)
+    rows = ops.pw_bwd_virt(grad, (y_in, c_in, True), wdw, c_dw, True, w, g_in, scr, st, B, Hi, Wi, K, N)
+    assert 0 < rows <= rows_max
+    assert torch.equal(g_in, g_ref)
+    dw_a = scr[: rows * N * K].view(rows, N * K).double().sum(0)
+    dw_b = scr_ref[: rows_r * N * K].view(rows_r, N * K).double().sum(0)
+    close(dw_a, dw_b, 1e-5, "weight gradient")
+    a1, a2 = slab_stats(st, rows, K)
+    b1, b2 = slab_stats(st_ref, rows_r, K)
+    close(a1, b1, 1e-5, "sum g")
+    close(a2, b2, 1e-5, "sum g*xhat")
 
 
 def check_epilogue(g_in, scratch, rows, row_stride, col0, g_ref_nchw, ya_nchw, ca, relu_a, C):
