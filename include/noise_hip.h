@@ -123,6 +123,52 @@ typedef struct {
 } noise_fold_job;
 int noise_fold_jobs(const noise_fold_job* jobs, int njobs, int max_cols, void* stream);
 
+/* ---- waveform augmentation of the training data module: train/data.py:439-461 (chain), :418-424 (what the clean
+ * clip keeps), :186-209 (ImpulseResponse.apply), :30-57 (Cut), :133-157 (noise scaling and tiling, as the reference
+ * restates audiomentations' AddBackgroundNoise); process/process.py:69-75 (add_pyreverb) -------------------------- */
+/* Parameters of one (noisy, clean) pair, drawn by the caller. */
+typedef struct {
+  int src;        /* row of noisy_src / clean_src */
+  int shift;      /* Shift(rollover=False): samples moved towards later times (negative: earlier), vacated ones zero */
+  float gain;     /* Gain: amplitude ratio 10^(dB/20), noisy clip only */
+  float snr_db;   /* AddBackgroundNoise */
+  long noise_off; /* first sample of the noise segment in noise_pool */
+  int noise_len;  /* its length, <= L (0: no noise); a shorter segment repeats periodically (data.py:150-154) */
+  int ir;         /* impulse response of the pool, -1: ImpulseResponse not applied */
+  int ir_row;     /* row of the `mixed` / spectrum / reverb workspaces this clip uses, -1 without impulse response */
+  int cut;        /* Cut: first sample of the output window, cut + length <= L */
+  int invert;     /* PolarityInversion, noisy clip only */
+} noise_aug_item;
+/* Uniformly partitioned FFT convolution (overlap-save, blocks of noise_fir_block() = 1024 samples, 2048-point real
+ * transforms).  noise_fir_spectra: x [n_rows] rows x_stride floats apart, L samples each -> spec
+ * [n_rows][noise_fir_blocks(L)][1024][2]; filter = 0: segment k = samples (k-1)*1024 .. (k+1)*1024 (zeros outside the
+ * row), filter = 1: segment k = partition k followed by 1024 zeros.  tw1 [1024][2] = e^{-2 pi i j/1024}, tw2 [1025][2] =
+ * e^{-2 pi i k/2048}.
+ * noise_fir_apply: y[row][0..L) = (x * h)[0..L), the convolution truncated to the input length as data.py:191-192 and
+ * process.py:70-73 truncate fftconvolve(mode="full"); row uses impulse response ir_of_row[row] of a pool of n_ir, whose
+ * spectra (noise_fir_spectra with filter = 1) start at block ir_first_block[i] of hspec and span ir_nblk[i] blocks.
+ * partial (optional) [n_rows][noise_fir_partials(L)] receives sums of squares of y. */
+int noise_fir_block(void);
+int noise_fir_blocks(long L);
+int noise_fir_partials(long L);
+int noise_fir_spectra(const float* x, long x_stride, int n_rows, long L, int filter, const float* tw1, const float* tw2,
+                      float* spec, void* stream);
+int noise_fir_apply(const float* xspec, int n_rows, long L, const int* ir_of_row, const float* hspec,
+                    const long* ir_first_block, const int* ir_nblk, int n_ir, const float* tw1, const float* tw2, float* y,
+                    long y_stride, double* partial, void* stream);
+/* Gain, Shift, AddBackgroundNoise of every item (items: DEVICE array).  Items with ir < 0 leave through Cut,
+ * PolarityInversion and Clip into out_noisy [n_items][length]; the others write the whole mixed clip to
+ * mixed[ir_row][L].  out_clean [n_items][length] = Cut(Shift(clean)).  partial: n_items * noise_aug_chunks(L) * 3
+ * doubles (kept for noise_aug_finish). */
+int noise_aug_chunks(long L);
+int noise_aug_mix(const noise_aug_item* items, int n_items, const float* noisy_src, const float* clean_src,
+                  long src_stride, long L, const float* noise_pool, long noise_pool_len, double* partial, float* mixed,
+                  float* out_noisy, float* out_clean, int length, void* stream);
+/* data.py:194-208 after the convolution (RMS of the input restored, clip), then Cut, PolarityInversion, Clip, for the
+ * n_rows convolved clips: reverb [n_rows][L] and rev_partial from noise_fir_apply, item_of_row [n_rows] their items. */
+int noise_aug_finish(const noise_aug_item* items, const int* item_of_row, int n_rows, const float* reverb, long L,
+                     const double* mix_partial, const double* rev_partial, float* out_noisy, int length, void* stream);
+
 /* ---- SNR mixer: process/audiolib.py:176-216 (+ :219-248, :30-35, :18-19), :251-289 ---------- */
 /* clean, noise [U][L] float64 (already length-matched); snr, level_draw [U]; outputs [U][L], level_out [U] */
 int noise_snr_mix(const double* clean, const double* noise, const int* snr, const int* level_draw,

@@ -12,6 +12,8 @@ before the import.  The stand-ins restate public library semantics only:
 * librosa.util.pad_center/normalize  -> symmetric zero pad / identity for norm=None
 * torchvision.ops.misc.ConvNormActivation / Conv2dNormActivation and
   torchvision.models._utils._make_divisible (torchvision 0.16 semantics)
+* audiomentations (train/data.py only): BaseWaveformTransform, load_sound_file over named in-memory arrays,
+  calculate_rms, calculate_desired_noise_rms, find_audio_files_in_paths; boto3 as an empty module
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -298,6 +300,100 @@ def mrstft_fixture(models, path):
     np.savez(path, **g5)
 
 
+def _install_augment_standins(sounds):
+    """audiomentations is not installed: train/data.py gets its base class and helpers as stand-ins that restate the
+    library's published behaviour (a transform holds `p`, a `parameters` dict whose "should_apply" is drawn by
+    randomize_parameters, and a frozen flag; calculate_rms = sqrt(mean(square)); calculate_desired_noise_rms =
+    clean_rms / 10^(snr/20)).  "Sound files" are arrays registered under a name."""
+    import random
+
+    class BaseWaveformTransform:
+        def __init__(self, p=0.5):
+            self.p = p
+            self.parameters = {"should_apply": None}
+            self.are_parameters_frozen = False
+
+        def randomize_parameters(self, samples, sample_rate):
+            self.parameters["should_apply"] = random.random() < self.p
+
+    class BaseCompose:
+        pass
+
+    def load_sound_file(path, sample_rate, mono=True):
+        return sounds[path], sample_rate
+
+    def calculate_rms(samples):
+        return np.sqrt(np.mean(np.square(samples)))
+
+    def calculate_desired_noise_rms(clean_rms, snr):
+        return clean_rms / (10 ** (float(snr) / 20))
+
+    def find_audio_files_in_paths(paths, **kw):
+        return list(paths) if isinstance(paths, (list, tuple)) else [paths]
+
+    am = types.ModuleType("audiomentations")
+    core = types.ModuleType("audiomentations.core")
+    alu = types.ModuleType("audiomentations.core.audio_loading_utils")
+    ti = types.ModuleType("audiomentations.core.transforms_interface")
+    comp = types.ModuleType("audiomentations.core.composition")
+    ut = types.ModuleType("audiomentations.core.utils")
+    alu.load_sound_file = load_sound_file
+    ti.BaseWaveformTransform = BaseWaveformTransform
+    comp.BaseCompose = BaseCompose
+    ut.calculate_rms = calculate_rms
+    ut.calculate_desired_noise_rms = calculate_desired_noise_rms
+    ut.find_audio_files_in_paths = find_audio_files_in_paths
+    for name, mod in [("audiomentations", am), ("audiomentations.core", core),
+                      ("audiomentations.core.audio_loading_utils", alu),
+                      ("audiomentations.core.transforms_interface", ti),
+                      ("audiomentations.core.composition", comp), ("audiomentations.core.utils", ut),
+                      ("boto3", types.ModuleType("boto3"))]:
+        sys.modules[name] = mod
+
+
+def augment_fixture(path):
+    """G6: the reference's own augmentation arithmetic on synthetic sounds: `ImpulseResponse.apply`, `Cut.apply` and
+    `JustNoise.apply` (the scaling and tiling AddBackgroundNoise shares) of train/data.py, `add_pyreverb` of
+    process/process.py."""
+    rng = np.random.RandomState(600)
+    L = 40000
+    env = 0.5 * (1 - np.cos(2 * np.pi * 4 * np.arange(L) / 16000.0))
+    speech = (rng.randn(L) * 0.1 * env).astype(np.float32)
+    sounds = {}
+    for name, n, decay in (("ir_short", 700, 120.0), ("ir_room", 5000, 900.0), ("ir_hall", 17000, 4000.0)):
+        h = rng.randn(n) * np.exp(-np.arange(n) / decay)
+        h[0] = 1.0
+        sounds[name] = h.astype(np.float32)
+    sounds["noise_long"] = (rng.randn(L + 9000) * 0.03).astype(np.float32)
+    sounds["noise_short"] = (rng.randn(6100) * 0.2).astype(np.float32)
+    _install_augment_standins(sounds)
+    import data  # noqa: train/data.py, untouched
+    import process  # noqa: process/process.py, untouched
+
+    g6 = {"speech": speech}
+    for k, v in sounds.items():
+        g6[k] = v
+    for name in ("ir_short", "ir_room", "ir_hall"):
+        t = data.ImpulseResponse(sounds_path=[name], p=0.5)
+        t.parameters["ir_file_path"] = name
+        g6[f"impulse_response_{name}"] = t.apply(speech.copy(), 16000)
+        g6[f"add_pyreverb_{name}"] = process.add_pyreverb(speech.copy(), sounds[name])
+    for tag, sound, start, snr in (("long", "noise_long", 1234, 7.5), ("short", "noise_short", 0, -3.0)):
+        t = data.JustNoise(sounds_path=[sound], min_snr_db=-5.0, max_snr_db=20.0, p=1.0)
+        t.parameters.update(snr_db=snr, noise_file_path=sound, noise_start_index=start, noise_end_index=start + L)
+        g6[f"noise_{tag}_scaled"] = t.apply(speech.copy(), 16000)
+        g6[f"noise_{tag}_params"] = np.array([start, snr], dtype=np.float64)
+    for tag, is_val, offset in (("train", False, 3111), ("val", True, None)):
+        t = data.Cut(length=8000, is_val=is_val, p=1.0)
+        if offset is None:
+            t.randomize_parameters(speech, 16000)
+        else:
+            t.parameters["offset"] = offset
+        g6[f"cut_{tag}"] = t.apply(speech.copy(), 16000)
+        g6[f"cut_{tag}_offset"] = np.int64(t.parameters["offset"])
+    np.savez(path, **g6)
+
+
 def main():
     _install_standins()
     sys.path.insert(0, os.path.join(REF, "train"))
@@ -307,6 +403,9 @@ def main():
 
     if "--only-g5" in sys.argv:         # the other fixtures stay as committed
         mrstft_fixture(models, os.path.join(OUT, "g5_mrstft.npz"))
+        return
+    if "--only-g6" in sys.argv:
+        augment_fixture(os.path.join(OUT, "g6_augment.npz"))
         return
 
     # ------------------------------------------------------------------ G1: STFT fwd / inv
@@ -399,6 +498,9 @@ def main():
 
     # ------------------------------------------------------------------ G5: multi-resolution STFT loss
     mrstft_fixture(models, os.path.join(OUT, "g5_mrstft.npz"))
+
+    # ------------------------------------------------------------------ G6: waveform augmentation
+    augment_fixture(os.path.join(OUT, "g6_augment.npz"))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:32s} {os.path.getsize(os.path.join(OUT, f)):>9d} B")
