@@ -9,12 +9,23 @@ enum { ACT_NONE = 0, ACT_RELU6 = 1 };
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
-__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
-  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+// Packed fp32 arithmetic: two lanes of a float4 per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); every
+// operation is the IEEE one, so results equal the scalar forms bit for bit.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ float4 pack4(f32x2 lo, f32x2 hi) { return make_float4(lo.x, lo.y, hi.x, hi.y); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) {
+  return pack4(f32x2{a.x, a.y} + f32x2{b.x, b.y}, f32x2{a.z, a.w} + f32x2{b.z, b.w});
 }
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) {
+  return pack4(f32x2{a.x, a.y} * f32x2{b.x, b.y}, f32x2{a.z, a.w} * f32x2{b.z, b.w});
+}
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return pack4(__builtin_elementwise_fma(f32x2{a.x, a.y}, f32x2{b.x, b.y}, f32x2{c.x, c.y}),
+               __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{b.z, b.w}, f32x2{c.z, c.w}));
+}
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
+  return pack4(f32x2{a.x, a.y} - f32x2{b.x, b.y}, f32x2{a.z, a.w} - f32x2{b.z, b.w});
+}
 __device__ __forceinline__ float4 relu6_4(float4 v) { return make_float4(relu6f(v.x), relu6f(v.y), relu6f(v.z), relu6f(v.w)); }
 
 // Per-thread view of one lazy source restricted to 4 consecutive channels c..c+3.
@@ -26,9 +37,10 @@ struct Lazy4 {
   bool present;
 };
 
+// min(max(v, lo), hi) as one median-of-three per lane (lo <= hi; the bounds may be infinite)
 __device__ __forceinline__ float4 clamp4(float4 v, float lo, float hi) {
-  return make_float4(fminf(fmaxf(v.x, lo), hi), fminf(fmaxf(v.y, lo), hi), fminf(fmaxf(v.z, lo), hi),
-                     fminf(fmaxf(v.w, lo), hi));
+  return make_float4(__builtin_amdgcn_fmed3f(v.x, lo, hi), __builtin_amdgcn_fmed3f(v.y, lo, hi),
+                     __builtin_amdgcn_fmed3f(v.z, lo, hi), __builtin_amdgcn_fmed3f(v.w, lo, hi));
 }
 
 __device__ __forceinline__ Lazy4 lazy4_init(const LazySrc& s, int C, int c) {
