@@ -7,3 +7,4 @@ from .models import VADSpectralV2, VADMobileNetV2  # noqa: F401
 from .optim import FusedAdamW  # noqa: F401
 from .data import VADNoiseDataModule  # noqa: F401
 from .streaming import StreamingDenoiser  # noqa: F401
+from .augment import AugmentPools, VADTrainAugment, add_pyreverb, impulse_response  # noqa: F401

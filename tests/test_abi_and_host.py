@@ -30,7 +30,7 @@ def test_header_symbols_are_exported():
     lib.noise_version.restype = ctypes.c_int
     assert lib.noise_version() >= 100
     # every bound Python signature refers to a declared entry point
-    from noise_amd import _lib, ops, engine  # noqa: F401
+    from noise_amd import _lib, ops, engine, augment, losses  # noqa: F401
     assert set(_lib._SIGNATURES) <= set(names)
 
 
