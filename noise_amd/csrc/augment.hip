@@ -30,27 +30,12 @@ constexpr int FZP = FN2 + 1;    // LDS row pitch (complex elements)
 constexpr int FNT = FROWS * 32;
 constexpr int AUG_CH = 8192;    // samples per workgroup of the elementwise kernels
 
-constexpr size_t fir_smem() { return (size_t)FROWS * FZP * 8 + (size_t)FN2 * 8 + (size_t)(FN2 + 1) * 8; }
-
-__device__ __forceinline__ void fir_load_tables(const c32* __restrict__ tw1g, const c32* __restrict__ tw2g, c32* tw1, c32* tw2) {
-  const int tid = threadIdx.x;
-  c32 a[FN2 / FNT], b[FN2 / FNT];
-#pragma unroll
-  for (int u = 0; u < FN2 / FNT; ++u) {
-    a[u] = tw1g[tid + u * FNT];
-    b[u] = tw2g[tid + u * FNT];
-  }
-  const c32 last = tw2g[FN2];
-#pragma unroll
-  for (int u = 0; u < FN2 / FNT; ++u) {
-    tw1[tid + u * FNT] = a[u];
-    tw2[tid + u * FNT] = b[u];
-  }
-  if (tid == 0) tw2[FN2] = last;
-}
+// LDS holds the row buffer only: 8 rows x 1025 complex = 65.6 KB, two workgroups per CU.  The two twiddle tables (16 KB)
+// are read from global memory; they stay cache resident.
+constexpr size_t fir_smem() { return (size_t)FROWS * FZP * 8; }
 
 // Forward 1024-point transform of the rows of zbuf whose pass-A inputs the caller holds in v (thread = (row, j)).
-__device__ __forceinline__ void fir_fft_rows(c32 (&v)[32], c32* zrow, const c32* tw1, int j) {
+__device__ __forceinline__ void fir_fft_rows(c32 (&v)[32], c32* zrow, const c32* __restrict__ tw1, int j) {
   Dft<32>::run(v);
   zrow[j * 32] = v[0];
 #pragma unroll
@@ -66,12 +51,12 @@ struct SpecDims {
 };
 
 // spec[row][k][f], f < 1024: one-sided spectrum of segment k, bin 0 holding (DC, Nyquist).
-__global__ __launch_bounds__(FNT) void fir_spectra_kernel(const float* __restrict__ xg, const c32* __restrict__ tw1g,
+__global__ __launch_bounds__(FNT, 2) void fir_spectra_kernel(const float* __restrict__ xg, const c32* __restrict__ tw1g,
                                                           const c32* __restrict__ tw2g, c32* __restrict__ spec, SpecDims d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   c32* zbuf = reinterpret_cast<c32*>(lds_raw);
-  c32* tw1 = zbuf + FROWS * FZP;
-  c32* tw2 = tw1 + FN2;
+  const c32* tw1 = tw1g;
+  const c32* tw2 = tw2g;
   const int tid = threadIdx.x, row = tid >> 5, j = tid & 31;
   const int k0 = blockIdx.x * FROWS, k = k0 + row;
   const float* x = xg + (size_t)blockIdx.y * d.x_stride;
@@ -87,8 +72,6 @@ __global__ __launch_bounds__(FNT) void fir_spectra_kernel(const float* __restric
     const float a = x[min(max(g0, 0L), d.L - 1)], b = x[min(max(g1, 0L), d.L - 1)];
     v[m2] = {ok0 ? a : 0.f, ok1 ? b : 0.f};
   }
-  fir_load_tables(tw1g, tw2g, tw1, tw2);
-  __syncthreads();
   fir_fft_rows(v, zbuf + row * FZP, tw1, j);
   for (int r = 0; r < FROWS; ++r) {
     if (k0 + r >= d.nblk) break;
@@ -123,29 +106,33 @@ __device__ __forceinline__ c32 bin_mul(c32 x, c32 h, bool packed_reals) {
 
 struct ApplyDims {
   long L, y_stride;
-  int nblk, n_ir;
+  int nblk, n_ir, n_rows, ntiles;
 };
 
-__global__ __launch_bounds__(FNT) void fir_apply_kernel(const c32* __restrict__ xspec, const int* __restrict__ ir_of_row,
+__global__ __launch_bounds__(FNT, 2) void fir_apply_kernel(const c32* __restrict__ xspec, const int* __restrict__ ir_of_row,
                                                         const c32* __restrict__ hspec, const long* __restrict__ ir_first_block,
                                                         const int* __restrict__ ir_nblk, const c32* __restrict__ tw1g,
                                                         const c32* __restrict__ tw2g, float* __restrict__ yg,
                                                         double* __restrict__ partial, ApplyDims d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   c32* zbuf = reinterpret_cast<c32*>(lds_raw);
-  c32* tw1 = zbuf + FROWS * FZP;
-  c32* tw2 = tw1 + FN2;
+  const c32* tw1 = tw1g;
+  const c32* tw2 = tw2g;
   __shared__ double red[FNT / 64];
   const int tid = threadIdx.x;
-  const int b = blockIdx.y, k0 = blockIdx.x * FROWS;
+  // The workgroups of a clip read overlapping windows of its spectra (every block 2-3 times with a 1 s filter):
+  // consecutive virtual indices run on one XCD, so those re-reads meet in one L2 instead of going to HBM from eight.
+  const int vblk = xcd_chunked_block();
+  if (vblk >= d.n_rows * d.ntiles) return;
+  const int b = vblk / d.ntiles, tile = vblk - b * d.ntiles, k0 = tile * FROWS;
   const int ir = min(max(ir_of_row[b], 0), d.n_ir - 1);
   const int P = ir_nblk[ir];
   const c32* H = hspec + (size_t)ir_first_block[ir] * FN2;
   const c32* X = xspec + (size_t)b * d.nblk * FN2;
-  fir_load_tables(tw1g, tw2g, tw1, tw2);
-  __syncthreads();
-  for (int k = tid; k <= FN2 / 2; k += FNT) {
-    const int kb = k == 0 ? 0 : FN2 - k;
+  // 513 bin pairs (k, 1024 - k) over 256 threads in two rounds: the thread that takes the packed bin 0 (DC and Nyquist,
+  // two real products) carries the self-paired bin 512 in its second accumulator set instead of a copy of bin 0
+  for (int k = tid; k < FN2 / 2; k += FNT) {
+    const int kb = k == 0 ? FN2 / 2 : FN2 - k;
     const bool packed = k == 0;
     c32 ya[FROWS], yb[FROWS], xa[FROWS], xb[FROWS];
 #pragma unroll
@@ -183,7 +170,7 @@ __global__ __launch_bounds__(FNT) void fir_apply_kernel(const c32* __restrict__ 
         for (int r = 0; r < FROWS; ++r) {
           const int s = (r - u) & (FROWS - 1);
           ya[r] = cadd(ya[r], bin_mul(xa[s], ha[u], packed));
-          yb[r] = cadd(yb[r], bin_mul(xb[s], hb[u], packed));
+          yb[r] = cadd(yb[r], cmul(xb[s], hb[u]));
         }
         xa[(FROWS - 1 - u) & (FROWS - 1)] = na[u];
         xb[(FROWS - 1 - u) & (FROWS - 1)] = nb[u];
@@ -197,6 +184,7 @@ __global__ __launch_bounds__(FNT) void fir_apply_kernel(const c32* __restrict__ 
       c32* zr = zbuf + r * FZP;
       if (packed) {
         zr[0] = {0.5f * (ya[r].x + ya[r].y), -0.5f * (ya[r].x - ya[r].y)};
+        zr[FN2 / 2] = yb[r];   // Z[512] = conj(Y[512]), stored conjugated
       } else {
         const c32 e = {0.5f * (ya[r].x + yb[r].x), 0.5f * (ya[r].y - yb[r].y)};
         const c32 df = {0.5f * (ya[r].x - yb[r].x), 0.5f * (ya[r].y + yb[r].y)};
@@ -238,7 +226,7 @@ __global__ __launch_bounds__(FNT) void fir_apply_kernel(const c32* __restrict__ 
     if (tid == 0) {
       double s = 0.0;
       for (int wv = 0; wv < FNT / 64; ++wv) s += red[wv];
-      partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+      partial[(size_t)b * d.ntiles + tile] = s;
     }
   }
 }
@@ -403,8 +391,9 @@ NOISE_EXPORT int noise_fir_apply(const float* xspec, int n_rows, long L, const i
   NOISE_REQUIRE(L > 0 && y_stride >= L && n_ir > 0, "noise_fir_apply: L=%ld y_stride=%ld n_ir=%d", L, y_stride, n_ir);
   const size_t smem = fir_smem();
   NOISE_ALLOW_LDS(fir_apply_kernel, smem);
-  ApplyDims d{L, y_stride, noise_fir_blocks(L), n_ir};
-  hipLaunchKernelGGL(fir_apply_kernel, dim3(noise_cdiv(d.nblk, FROWS), n_rows), dim3(FNT), smem, (hipStream_t)stream,
+  ApplyDims d{L, y_stride, noise_fir_blocks(L), n_ir, n_rows, noise_fir_partials(L)};
+  NOISE_REQUIRE((long)n_rows * d.ntiles < (1L << 30), "noise_fir_apply: %d rows of %d tiles exceed the grid", n_rows, d.ntiles);
+  hipLaunchKernelGGL(fir_apply_kernel, dim3(noise_pad8((long)n_rows * d.ntiles)), dim3(FNT), smem, (hipStream_t)stream,
                      (const c32*)xspec, ir_of_row, (const c32*)hspec, ir_first_block, ir_nblk, (const c32*)tw1, (const c32*)tw2, y,
                      partial, d);
   NOISE_CHECK_LAUNCH("noise_fir_apply");

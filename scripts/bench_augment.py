@@ -4,13 +4,14 @@ usage: python scripts/bench_augment.py [B] [ir_seconds] [--cpu]
 Prints per-entry-point times (HIP events on the launch stream), the whole-batch rate in audio-seconds of source clip
 per second, and with --cpu the numpy oracle's rate on a bounded sample of the same items (one core)."""
 import json
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from noise_amd import _lib, augment  # noqa: E402
 
 
