@@ -121,6 +121,73 @@ def other_configs(device):
             m.model._plans.clear()
         del m
         torch.cuda.empty_cache()
+    out.update(stream_mix_augment_configs(device))
+    return out
+
+
+def stream_mix_augment_configs(device):
+    """configs[3] (streaming window driver, worker.js protocol: 0.2 s of new audio per stream and hop; latency of one
+    stream, throughput of 1024, bf16 model path, HIP-graph replay), configs[4] (SNR mixing of 1024 utterance pairs of
+    10 s in float64) and the waveform augmentation of the data module (256 pairs of 10 s, 1 s impulse responses)."""
+    import numpy as np
+    from noise_amd import StreamingDenoiser, augment, mixer
+    out = {}
+    m = build_model(device).eval()
+    m.inference_dtype = "bf16"
+    for n in (1, 1024):
+        s = StreamingDenoiser(m, n)
+        block = torch.randn(n, 3200, device=device) * 0.05
+        for _ in range(5):
+            s.push_block(block)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(200 if n == 1 else 30):
+            t0 = time.perf_counter()
+            s.push_block(block)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        lat.sort()
+        p50, p99 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(len(lat) * 0.99))]
+        out[f"stream_bf16_320_160_n{n}"] = {"hop_ms_p50": round(1e3 * p50, 3), "hop_ms_p99": round(1e3 * p99, 3),
+                                            "audio_s_per_s": round(n * 0.2 / p50, 1)}
+        del s
+        m.model._plans.clear()
+    del m
+    U, L = 1024, 160000
+    g = torch.Generator(device="cpu").manual_seed(3)
+    clean = (torch.randn(U, L, generator=g, dtype=torch.float64) * 0.05).to(device)
+    noise = (torch.randn(U, L, generator=g, dtype=torch.float64) * 0.02).to(device)
+    snr = torch.randint(-5, 20, (U,), generator=g).to(device)
+    level = torch.randint(-35, -15, (U,), generator=g).to(device)
+    for _ in range(2):
+        mixer.mix_batch(clean, noise, snr, level)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        mixer.mix_batch(clean, noise, snr, level)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    out["mix_f64_1024x10s"] = {"audio_s_per_s": round(U * 10 / dt, 1), "GB_per_s": round(56 * L * U / dt / 1e9, 1)}
+    del clean, noise
+    torch.cuda.empty_cache()
+    rng = np.random.RandomState(0)
+    N, B = 64, 256
+    cl = (rng.randn(N, L) * 0.05).astype(np.float32)
+    ny = (cl + rng.randn(N, L).astype(np.float32) * 0.02).astype(np.float32)
+    irs = [(rng.randn(16000) * np.exp(-np.arange(16000) / 3200.0)).astype(np.float32) for _ in range(8)]
+    pools = augment.AugmentPools(ny, cl, [(rng.randn(3 * L) * 0.05).astype(np.float32)], irs, device)
+    t = augment.VADTrainAugment(pools, 8000, p=0.5, seed=0)
+    items = t.draw([i % N for i in range(B)])
+    for _ in range(3):
+        t.apply(items)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        t.apply(items)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    out["augment_256x10s_ir1s"] = {"ms_per_batch": round(1e3 * dt, 3), "audio_s_per_s": round(B * 10 / dt, 1),
+                                   "with_impulse_response": int((items["ir"] >= 0).sum())}
     return out
 
 
