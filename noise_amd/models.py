@@ -49,6 +49,23 @@ except Exception:  # pragma: no cover - depends on the environment
         def log_dict(self, d, **kw):
             self.logged_metrics = dict(d)
 
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **overrides):
+            """`LightningModule.load_from_checkpoint` as train/export.py:8 uses it: a Lightning checkpoint is a dict with
+            "hyper_parameters" (the constructor arguments `save_hyperparameters` recorded) and "state_dict".  The file is
+            read with `weights_only=True` (tensors and plain containers only, nothing in it is executed)."""
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=True)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.update(overrides)
+            model = cls(**hp)
+            model.load_state_dict(ckpt["state_dict"], strict=strict)
+            return model
+
+        def save_checkpoint(self, checkpoint_path, **extra):
+            """Writes the two entries of a Lightning checkpoint that `load_from_checkpoint` reads."""
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+            torch.save({"hyper_parameters": dict(self.hparams), "state_dict": sd, **extra}, checkpoint_path)
+
 
 class _AttrDict(dict):
     __getattr__ = dict.__getitem__

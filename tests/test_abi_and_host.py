@@ -146,3 +146,27 @@ def test_synthetic_datamodule_contract():
     other_rank = next(iter(VADNoiseDataModule(length=8000, num_samples=64, batch_size=16, device="cpu", rank=1,
                                               world_size=2).train_dataloader()))
     assert not torch.equal(other_rank[0], noisy)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """`load_from_checkpoint` (train/export.py:8) reads the "hyper_parameters" and "state_dict" entries of a Lightning
+    checkpoint with a loader that executes nothing from the file."""
+    import torch
+    from noise_amd import VADSpectralV2
+    lc = [[1, 32, 1, [3, 3], [2, 2]], [1, 16, 1, [3, 3], [1, 1]], [3, 24, 1, [3, 3], [2, 2]], [3, 32, 1, [3, 3], [2, 2]],
+          [3, 64, 1, [3, 3], [2, 2]]]
+    torch.manual_seed(3)
+    m = VADSpectralV2(n_fft=320, hop_length=160, win_length=320, window="hann", nhead=6, num_layers=1, dropout=0.0,
+                      layer_config=lc, pad_value=-1, max_frames=40)
+    if not hasattr(m, "save_checkpoint"):
+        pytest.skip("Lightning is installed: its own checkpoint I/O applies")
+    path = str(tmp_path / "spectralv2.ckpt")
+    m.save_checkpoint(path, epoch=192)
+    torch.manual_seed(99)
+    m2 = VADSpectralV2.load_from_checkpoint(path)
+    assert dict(m2.hparams) == dict(m.hparams) and m2.hparams.max_frames == 40
+    sd, sd2 = m.state_dict(), m2.state_dict()
+    assert list(sd) == list(sd2) and len(sd) == 159
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+    m3 = VADSpectralV2.load_from_checkpoint(path, max_frames=40, pad_value=-1)
+    assert m3.hparams.pad_value == -1
