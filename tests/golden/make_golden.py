@@ -394,6 +394,80 @@ def augment_fixture(path):
     np.savez(path, **g6)
 
 
+def synth_files_fixture(path):
+    """G7: the reference's `build_audio` / `gen_audio` (process/process.py:78-199) over a small set of synthetic 16 kHz
+    PCM wav files.  `soundfile.read` is a stand-in over the standard `wave` module (16-bit PCM -> float64 / 32768, what
+    libsndfile returns for such a file); the activity detector is the reference's own."""
+    import random
+    import tempfile
+    import wave
+
+    def sf_read(p, start=0, stop=None):
+        with wave.open(p, "rb") as f:
+            fs = f.getframerate()
+            raw = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2")
+        return raw.astype(np.float64)[start:stop] / 32768.0, fs
+
+    sys.modules["soundfile"].read = sf_read
+    import audiolib  # noqa
+    import process  # noqa
+    audiolib.sf.read = sf_read
+    rng = np.random.RandomState(700)
+    root = tempfile.mkdtemp()
+    g7 = {}
+    names = {"clean": [], "noise": []}
+    for kind, n, scale in (("clean", 7, 0.12), ("noise", 5, 0.05)):
+        for i in range(n):
+            L = int(rng.randint(2500, 14000))
+            env = 0.5 * (1 - np.cos(2 * np.pi * 3 * np.arange(L) / 16000.0 + rng.rand() * 6.28))
+            x = rng.randn(L) * scale * (env if kind == "clean" else 1.0)
+            if kind == "clean" and i == 2:
+                x[100:110] = 1.2          # a clipped file: skipped by build_audio
+            if kind == "clean" and i == 4:
+                x *= 0.001                # nearly silent: rejected by the activity threshold
+            pcm = np.clip(np.rint(x * 32768.0), -32768, 32767).astype("<i2")
+            name = f"{kind}_{i}.wav"
+            with wave.open(os.path.join(root, name), "wb") as f:
+                f.setnchannels(1)
+                f.setsampwidth(2)
+                f.setframerate(16000)
+                f.writeframes(pcm.tobytes())
+            g7[f"src_{name}"] = pcm
+            names[kind].append(name)
+    params = dict(fs=16000, silence_length=0.05, audio_length=1.5, is_test_set=False, audioformat="*.wav",
+                  cleanfilenames=[os.path.join(root, n) for n in names["clean"]],
+                  noisefilenames=[os.path.join(root, n) for n in names["noise"]],
+                  clean_activity_threshold=0.0, noise_activity_threshold=0.0)
+    g7["clean_names"] = np.array(names["clean"])
+    g7["noise_names"] = np.array(names["noise"])
+    base = lambda fl: np.array([os.path.basename(f) for f in fl])
+    case = 0
+    for is_clean, index, length, test_set in ((True, 0, -1, False), (True, 3, 30000, False), (False, 1, 20000, False),
+                                              (True, 5, 9000, True), (False, 4, -1, False)):
+        params["is_test_set"] = test_set
+        np.random.seed(40 + case)
+        random.seed(40 + case)
+        audio, used, clipped, idx = process.build_audio(is_clean, params, index, length)
+        g7[f"build{case}_args"] = np.array([int(is_clean), index, length, int(test_set), 40 + case])
+        g7[f"build{case}_audio"] = np.asarray(audio, dtype=np.float64)
+        g7[f"build{case}_used"] = base(used)
+        g7[f"build{case}_clipped"] = base(clipped)
+        g7[f"build{case}_idx"] = np.int64(idx)
+        case += 1
+    params["is_test_set"] = False
+    params["clean_activity_threshold"] = 0.6
+    np.random.seed(77)
+    random.seed(77)
+    audio, used, clipped, low, idx = process.gen_audio(True, params, 2, 16000)
+    g7["gen_audio"] = np.asarray(audio, dtype=np.float64)
+    g7["gen_used"] = base(used)
+    g7["gen_clipped"] = base(clipped)
+    g7["gen_low_activity"] = base(low)
+    g7["gen_idx"] = np.int64(idx)
+    g7["gen_activity"] = np.float64(audiolib.activitydetector(audio))
+    np.savez_compressed(path, **g7)
+
+
 def main():
     _install_standins()
     sys.path.insert(0, os.path.join(REF, "train"))
@@ -406,6 +480,9 @@ def main():
         return
     if "--only-g6" in sys.argv:
         augment_fixture(os.path.join(OUT, "g6_augment.npz"))
+        return
+    if "--only-g7" in sys.argv:
+        synth_files_fixture(os.path.join(OUT, "g7_synth_files.npz"))
         return
 
     # ------------------------------------------------------------------ G1: STFT fwd / inv
@@ -501,6 +578,9 @@ def main():
 
     # ------------------------------------------------------------------ G6: waveform augmentation
     augment_fixture(os.path.join(OUT, "g6_augment.npz"))
+
+    # ------------------------------------------------------------------ G7: file-based audio building
+    synth_files_fixture(os.path.join(OUT, "g7_synth_files.npz"))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:32s} {os.path.getsize(os.path.join(OUT, f)):>9d} B")
