@@ -36,12 +36,14 @@ struct CellTiles {
   long ncells, ntiles;
   int Hi, Wi;
   int sb, sm, sx;   // 16 * gridDim.x cells as (images, rows, columns)
-  __device__ __forceinline__ CellTiles(const VirtDims& d) {
+  long tstep;        // tiles between two consecutive tiles of one walker
+  __device__ __forceinline__ CellTiles(const VirtDims& d, int tiles_per_block = 1) {
     ncells = d.ncells;
     ntiles = (ncells + 15) >> 4;
     Hi = d.Hi;
     Wi = d.Wi;
-    const unsigned per_src = (unsigned)Hi * (unsigned)Wi, step = 16u * gridDim.x;
+    tstep = (long)tiles_per_block * gridDim.x;
+    const unsigned per_src = (unsigned)Hi * (unsigned)Wi, step = 16u * (unsigned)tstep;
     sb = (int)(step / per_src);
     const unsigned rem = step - (unsigned)sb * per_src;
     sm = (int)(rem / (unsigned)Wi);
@@ -59,7 +61,7 @@ struct CellTiles {
     return t;
   }
   __device__ __forceinline__ void advance(TilePos& t) const {
-    t.tile += gridDim.x;
+    t.tile += tstep;
     if (t.tile >= ntiles) return;
     t.x += sx;
     if (t.x >= Wi) {
@@ -93,12 +95,14 @@ struct CellTiles {
   }
 };
 
-// Forward.  A workgroup walks tiles of 16 consecutive source cells; each of its four waves takes one parity class
-// (py, px) of the 64 output pixels a tile produces, rotating with the tile so that the classes' unequal work (1, 2, 2
-// and 4 source cells per output pixel) evens out.  Lane (p, q) builds the MFMA operand of output pixel (2m + py, 2x + px)
-// of cell p directly in registers (channels 16 jj + 4 q .. + 3), so nothing is staged through LDS.  The K channels are
-// processed in KH chunks of KCH 16-channel tiles: the raw source cells of the next chunk are requested before the MFMAs
-// of the current one.
+// Forward.  Each wave of a workgroup walks its own tiles of 16 consecutive source cells; a tile produces 64 output
+// pixels, the four parity classes (py, px) of every cell.  Lane (p, q) builds the MFMA operands of the four output pixels
+// (2m + py, 2x + px) of cell p directly in registers (channels 16 jj + 4 q .. + 3), so nothing is staged through LDS and
+// the 2x2 source window, its activation, the lazy coefficients and the weight fragments serve four pixels.  (One wave
+// per parity class, the first form of this kernel, read the coefficient and tap tables from LDS once per output pixel
+// and was bound by the LDS pipe: 0.27 ms for the 72 -> 16 layer of 1280 segments.)  The K channels are processed in KH
+// chunks of KCH 16-channel tiles; the registers of a consumed channel tile are refilled at once with the raw source cells
+// of the next chunk or tile.
 template <int KCH, int KH, int MT>
 __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const float* __restrict__ wdw, LazySrc Dw,
                                                              const float* __restrict__ W, float* __restrict__ out,
@@ -108,11 +112,11 @@ __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const f
   const int p = lane & 15, q = lane >> 4;
   const int K = d.K, N = d.N;
   constexpr int KC = KCH * KH, KP = KC * 16;
-  float* wfrag = lds;                    // [MT][KC][64][4]
-  float* cf = wfrag + MT * KC * 256;     // [4][KP]: scale_in, shift_in, scale_dw, shift_dw
-  float* wt = cf + 4 * KP;               // [9][KP]: the taps, tap-major
+  float* wfrag0 = lds;                    // [MT][KC][64][4]
+  float* cf0 = wfrag0 + MT * KC * 256;     // [4][KP]: scale_in, shift_in, scale_dw, shift_dw
+  float* wt0 = cf0 + 4 * KP;               // [9][KP]: the taps, tap-major
   if ((N & 15) || (K & 15)) {
-    for (int idx = tid; idx < MT * KC * 256; idx += 256) wfrag[idx] = 0.f;
+    for (int idx = tid; idx < MT * KC * 256; idx += 256) wfrag0[idx] = 0.f;
     __syncthreads();
   }
   {
@@ -121,17 +125,17 @@ __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const f
     for (int e = tid; e < N * K4; e += 256) {
       const int co = e / K4, ci = 4 * (e - co * K4);
       const float4 v = ld4(W + (size_t)co * K + ci);
-      st4(wfrag + ((((co >> 4) * KC + (ci >> 4)) * 64) + (co & 15) + 16 * ((ci & 15) >> 2)) * 4, v);
+      st4(wfrag0 + ((((co >> 4) * KC + (ci >> 4)) * 64) + (co & 15) + 16 * ((ci & 15) >> 2)) * 4, v);
     }
   }
   for (int k = tid; k < KP; k += 256) {
     const bool in = k < K;
-    cf[k] = (in && In.coef) ? In.coef[k] : 1.f;
-    cf[KP + k] = (in && In.coef) ? In.coef[K + k] : 0.f;
-    cf[2 * KP + k] = (in && Dw.coef) ? Dw.coef[k] : 1.f;
-    cf[3 * KP + k] = (in && Dw.coef) ? Dw.coef[K + k] : 0.f;
+    cf0[k] = (in && In.coef) ? In.coef[k] : 1.f;
+    cf0[KP + k] = (in && In.coef) ? In.coef[K + k] : 0.f;
+    cf0[2 * KP + k] = (in && Dw.coef) ? Dw.coef[k] : 1.f;
+    cf0[3 * KP + k] = (in && Dw.coef) ? Dw.coef[K + k] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t * KP + k] = in ? wdw[(size_t)k * 9 + t] : 0.f;    // depthwise weight (C, 1, 3, 3)
+    for (int t = 0; t < 9; ++t) wt0[t * KP + k] = in ? wdw[(size_t)k * 9 + t] : 0.f;    // depthwise weight (C, 1, 3, 3)
   }
   __syncthreads();
 
@@ -140,113 +144,102 @@ __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const f
   for (int m = 0; m < MT; ++m) s1[m] = s2[m] = f4(0.f);
   const float ilo = In.relu6 ? 0.f : -INFINITY, ihi = In.relu6 ? 6.f : INFINITY;
   const float dlo = Dw.relu6 ? 0.f : -INFINITY, dhi = Dw.relu6 ? 6.f : INFINITY;
-  const CellTiles ct(d);
-  const long iters = (ct.ntiles + gridDim.x - 1) / gridDim.x;
+  const CellTiles ct(d, 4);
+  const long iters = (ct.ntiles + 4L * gridDim.x - 1) / (4L * gridDim.x);
 
   // Source cells of a parity class in the order the stand-alone kernel sums them, with their taps:
   //   (0,0): (m,x) w4      (0,1): (m,x) w5, (m,x+1) w3      (1,0): (m,x) w7, (m+1,x) w1
   //   (1,1): (m,x) w8, (m,x+1) w6, (m+1,x) w2, (m+1,x+1) w0
+  // A wave owns a whole tile: lane (p, q) loads the 2x2 source window of cell p once (channels 16 jj + 4 q .. + 3),
+  // activates it once and builds its four output pixels from it, so the window, the lazy coefficients and the weight
+  // fragments are fetched once per four output pixels.  The channel tiles are walked one at a time; the registers of a
+  // consumed channel tile are refilled at once with the same tile of the next chunk (or of the wave's next tile).
   float4 r[KCH][4];
-  const float* nsrc = In.y;      // this lane's cell of the requested chunk
-  size_t no1 = 0, no2 = 0;       // offsets of the column / row neighbour (0 where the neighbour is not needed)
-  auto request = [&](const TilePos& t, int par, int h) {
+  auto request = [&](const TilePos& t, int h, int jj) {
     int b, m, x;
     ct.cell(t, p, b, m, x);
-    const int py = par >> 1, px = par & 1;
-    nsrc = In.y + (((size_t)b * d.Hi + m) * d.Wi + x) * K;
-    no1 = (px && x + 1 < d.Wi) ? (size_t)K : 0;
-    no2 = (py && m + 1 < d.Hi) ? (size_t)d.Wi * K : 0;
-    const int ns = (1 + py) * (1 + px);
-#pragma unroll
-    for (int jj = 0; jj < KCH; ++jj) {
-      const int ci = 16 * (h * KCH + jj) + 4 * q;
-      r[jj][0] = ld4(nsrc + (ci < K ? ci : 0));
-    }
-    if (ns > 1) {
-      const size_t o = px ? no1 : no2;
-#pragma unroll
-      for (int jj = 0; jj < KCH; ++jj) {
-        const int ci = 16 * (h * KCH + jj) + 4 * q;
-        r[jj][1] = ld4(nsrc + o + (ci < K ? ci : 0));
-      }
-    }
-    if (ns > 2) {
-#pragma unroll
-      for (int jj = 0; jj < KCH; ++jj) {
-        const int ci = 16 * (h * KCH + jj) + 4 * q;
-        r[jj][2] = ld4(nsrc + no2 + (ci < K ? ci : 0));
-        r[jj][3] = ld4(nsrc + no1 + no2 + (ci < K ? ci : 0));
-      }
-    }
+    const float* src = In.y + (((size_t)b * d.Hi + m) * d.Wi + x) * K;
+    const size_t no1 = (x + 1 < d.Wi) ? (size_t)K : 0, no2 = (m + 1 < d.Hi) ? (size_t)d.Wi * K : 0;
+    const int ci = 16 * (h * KCH + jj) + 4 * q, cc = ci < K ? ci : 0;
+    r[jj][0] = ld4(src + cc);
+    r[jj][1] = ld4(src + no1 + cc);
+    r[jj][2] = ld4(src + no2 + cc);
+    r[jj][3] = ld4(src + no1 + no2 + cc);
   };
-  auto build = [&](auto ns_tag, int par, int h, float4(&in)[KCH]) {
-    constexpr int NS = decltype(ns_tag)::value;
-    const int py = par >> 1, px = par & 1;
-    const int t0 = (py ? (px ? 8 : 7) : (px ? 5 : 4)) * KP, t1 = (NS == 4 ? 6 : (px ? 3 : 1)) * KP;
+  TilePos cur = ct.pos((long)blockIdx.x * 4 + wave), nxt = cur;
 #pragma unroll
-    for (int jj = 0; jj < KCH; ++jj) {
-      const int ci = 16 * (h * KCH + jj) + 4 * q;
-      const float4 sc = ld4(cf + ci), sh = ld4(cf + KP + ci);
-      float4 y = clamp4(fma4(r[jj][0], sc, sh), ilo, ihi) * ld4(wt + t0 + ci);
-      if (NS > 1) y = fma4(clamp4(fma4(r[jj][1], sc, sh), ilo, ihi), ld4(wt + t1 + ci), y);
-      if (NS > 2) {
-        y = fma4(clamp4(fma4(r[jj][2], sc, sh), ilo, ihi), ld4(wt + 2 * KP + ci), y);
-        y = fma4(clamp4(fma4(r[jj][3], sc, sh), ilo, ihi), ld4(wt + ci), y);
-      }
-      in[jj] = clamp4(fma4(y, ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci)), dlo, dhi);
-    }
-  };
-
-  TilePos cur = ct.pos(blockIdx.x), nxt = cur;
-  request(cur, wave & 3, 0);
+  for (int jj = 0; jj < KCH; ++jj) request(cur, 0, jj);
   for (long it = 0; it < iters; ++it) {
-    const int par = (wave + (int)it) & 3, py = par >> 1, px = par & 1;
     int b, m, x;
     const bool ex = ct.cell(cur, p, b, m, x);
-    const bool valid = ex && (!py || m + 1 < d.Hi) && (!px || x + 1 < d.Wi);
-    const size_t pix = ((size_t)b * d.Ho + 2 * m + py) * d.Wo + 2 * x + px;
-    f32x4 acc[MT];
+    const bool vy1 = m + 1 < d.Hi, vx1 = x + 1 < d.Wi;
+    const bool valid[4] = {ex, ex && vx1, ex && vy1, ex && vy1 && vx1};
+    f32x4 acc[4][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[cl][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ct.advance(nxt);
+    // The tables are read from LDS at every use: a lane's channels are the same for every tile, so the compiler would
+    // otherwise keep all of them (15 vectors per channel tile) in registers across the tile loop and spill.  An offset it
+    // cannot see through keeps the reads where they are.
+    int lofs = 0;
+    asm volatile("" : "+v"(lofs));
+    const float* cf = cf0 + lofs;
+    const float* wt = wt0 + lofs;
+    const float* wfrag = wfrag0 + lofs;
 #pragma unroll
     for (int h = 0; h < KH; ++h) {
-      float4 in[KCH];
-      if (par == 0) build(std::integral_constant<int, 1>{}, par, h, in);
-      else if (par == 3) build(std::integral_constant<int, 4>{}, par, h, in);
-      else build(std::integral_constant<int, 2>{}, par, h, in);
-      if (h + 1 < KH) {
-        request(cur, par, h + 1);
-      } else {
-        ct.advance(nxt);
-        request(nxt, (wave + (int)it + 1) & 3, 0);
-      }
 #pragma unroll
       for (int jj = 0; jj < KCH; ++jj) {
         const int ci = 16 * (h * KCH + jj) + 4 * q;
-        const bool okc = valid && ci < K;
-        in[jj] = make_float4(okc ? in[jj].x : 0.f, okc ? in[jj].y : 0.f, okc ? in[jj].z : 0.f, okc ? in[jj].w : 0.f);
-      }
+        const float4 sc = ld4(cf + ci), sh = ld4(cf + KP + ci);
+        const float4 s00 = clamp4(fma4(r[jj][0], sc, sh), ilo, ihi), s01 = clamp4(fma4(r[jj][1], sc, sh), ilo, ihi);
+        const float4 s10 = clamp4(fma4(r[jj][2], sc, sh), ilo, ihi), s11 = clamp4(fma4(r[jj][3], sc, sh), ilo, ihi);
+        if (h + 1 < KH) request(cur, h + 1, jj);
+        else request(nxt, 0, jj);
+        float4 y[4];
+        y[0] = s00 * ld4(wt + 4 * KP + ci);
+        y[1] = fma4(s01, ld4(wt + 3 * KP + ci), s00 * ld4(wt + 5 * KP + ci));
+        y[2] = fma4(s10, ld4(wt + 1 * KP + ci), s00 * ld4(wt + 7 * KP + ci));
+        y[3] = s00 * ld4(wt + 8 * KP + ci);
+        y[3] = fma4(s01, ld4(wt + 6 * KP + ci), y[3]);
+        y[3] = fma4(s10, ld4(wt + 2 * KP + ci), y[3]);
+        y[3] = fma4(s11, ld4(wt + ci), y[3]);
+        const float4 dsc = ld4(cf + 2 * KP + ci), dsh = ld4(cf + 3 * KP + ci);
+        float4 in[4];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+        for (int cl = 0; cl < 4; ++cl) {
+          const float4 a = clamp4(fma4(y[cl], dsc, dsh), dlo, dhi);
+          const bool okc = valid[cl] && ci < K;
+          in[cl] = make_float4(okc ? a.x : 0.f, okc ? a.y : 0.f, okc ? a.z : 0.f, okc ? a.w : 0.f);
+        }
 #pragma unroll
-        for (int jj = 0; jj < KCH; ++jj) {
+        for (int mt = 0; mt < MT; ++mt) {
           const float4 wa = ld4(wfrag + ((mt * KC + h * KCH + jj) * 64 + lane) * 4);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[jj].w, acc[mt], 0, 0, 0);
+#pragma unroll
+          for (int cl = 0; cl < 4; ++cl) {
+            acc[cl][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[cl].x, acc[cl][mt], 0, 0, 0);
+            acc[cl][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[cl].y, acc[cl][mt], 0, 0, 0);
+            acc[cl][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[cl].z, acc[cl][mt], 0, 0, 0);
+            acc[cl][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[cl].w, acc[cl][mt], 0, 0, 0);
+          }
         }
       }
     }
     cur = nxt;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co = 16 * mt + 4 * q;
-      const float4 o = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
-      if (valid && co < N) {
-        st4(out + pix * N + co, o);
-        s1[mt] = s1[mt] + o;
-        s2[mt] = fma4(o, o, s2[mt]);
+    for (int cl = 0; cl < 4; ++cl) {
+      const size_t pix = ((size_t)b * d.Ho + 2 * m + (cl >> 1)) * d.Wo + 2 * x + (cl & 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = 16 * mt + 4 * q;
+        const float4 o = make_float4(acc[cl][mt][0], acc[cl][mt][1], acc[cl][mt][2], acc[cl][mt][3]);
+        if (valid[cl] && co < N) {
+          st4(out + pix * N + co, o);
+          s1[mt] = s1[mt] + o;
+          s2[mt] = fma4(o, o, s2[mt]);
+        }
       }
     }
   }
@@ -598,7 +591,7 @@ NOISE_EXPORT int noise_pw_fwd_virt(const float* in_y, const float* in_coef, int 
   NOISE_REQUIRE(npix < (1L << 31) && (long)B * Hi * Wi * K < (1L << 40), "noise_pw_fwd_virt: tensor too large");
   VirtDims d{npix, K, N, Hi, Wi, Ho, Wo, (long)B * Hi * Wi};
   LazySrc In{in_y, in_coef, in_relu6}, Dw{nullptr, dw_coef, dw_relu6};
-  int grid = noise_grid((long)B * Hi * Wi, 16, 1024);
+  int grid = noise_grid((long)B * Hi * Wi, 64, 1024);   // four tiles of 16 cells per workgroup and iteration
   const int KC = (K + 15) / 16, MT = (N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
   if (KC == 5 && MT == 1) launch_virt<5, 1, 1>(In, wdw, Dw, w, out, stats_slab, d, grid, st);
