@@ -420,10 +420,28 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
       r[u][3] = ld4(src + o1 + o2);
     }
   };
+  // The input-gradient epilogue of a lane always works on the same channels (16 m2 + 4 q .. + 3): with few channel tiles
+  // its three coefficient vectors per tile stay in registers instead of being read from LDS for every pixel (the LDS
+  // pipe, not memory, bounds this kernel).
+  constexpr bool EPI_REGS = MTI <= 5;
+  float4 e_mean[EPI_REGS ? MTI : 1], e_mlo[EPI_REGS ? MTI : 1], e_istd[EPI_REGS ? MTI : 1];
+  __syncthreads();   // the tables are written
+  constexpr bool WF_REGS = EPI_REGS && KC == 1;   // the lane's weight fragments of the input gradient as well
+  float4 wf[WF_REGS ? MTI : 1];
+  if (EPI_REGS) {
+#pragma unroll
+    for (int m2 = 0; m2 < (EPI_REGS ? MTI : 0); ++m2) {
+      const int ci = 16 * m2 + 4 * q;
+      e_mean[m2] = ld4(cf + 4 * KP + ci);
+      e_istd[m2] = ld4(cf + 5 * KP + ci);
+      e_mlo[m2] = ld4(cf + 6 * KP + ci);
+      if (WF_REGS) wf[WF_REGS ? m2 : 0] = ld4(wfrag + (m2 * KC * 64 + lane) * 4);
+    }
+  }
   TilePos cur = ct.pos(blockIdx.x), nxt = cur;
   issue_tile(cur);
   for (long it = 0; it < iters; ++it) {
-    __syncthreads();   // the previous tile's MFMAs have read the staged tiles (first pass: the tables are written)
+    __syncthreads();   // the previous tile's MFMAs have read the staged tiles
 #pragma unroll
     for (int u = 0; u < PASS_N; ++u) {
       const int pp = 16 * (jn0 + JP * u) + in_cell;
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < KC; ++jj) {
-          const float4 wa = ld4(wfrag + ((m2 * KC + jj) * 64 + lane) * 4);
+          const float4 wa = WF_REGS ? wf[WF_REGS ? m2 : 0] : ld4(wfrag + ((m2 * KC + jj) * 64 + lane) * 4);
           o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[jj].x, o, 0, 0, 0);
           o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[jj].y, o, 0, 0, 0);
           o = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[jj].z, o, 0, 0, 0);
@@ -493,7 +511,8 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
             g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
             g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
           }
-          const float4 xh = sub4(sub4(yraw, ld4(cf + 4 * KP + ci)), ld4(cf + 6 * KP + ci)) * ld4(cf + 5 * KP + ci);
+          const float4 xh = EPI_REGS ? sub4(sub4(yraw, e_mean[EPI_REGS ? m2 : 0]), e_mlo[EPI_REGS ? m2 : 0]) * e_istd[EPI_REGS ? m2 : 0]
+                                     : sub4(sub4(yraw, ld4(cf + 4 * KP + ci)), ld4(cf + 6 * KP + ci)) * ld4(cf + 5 * KP + ci);
           s1[m2] = s1[m2] + g;
           s2[m2] = fma4(g, xh, s2[m2]);
           st4(g_in + prow + ci, g);
