@@ -166,6 +166,19 @@ __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const f
     r[jj][2] = ld4(src + no2 + cc);
     r[jj][3] = ld4(src + no1 + no2 + cc);
   };
+  // with few channel tiles the four lazy coefficient vectors of a lane's channels stay in registers
+  constexpr bool CF_REGS = KC <= 5;
+  float4 c_sc[CF_REGS ? KC : 1], c_sh[CF_REGS ? KC : 1], c_dsc[CF_REGS ? KC : 1], c_dsh[CF_REGS ? KC : 1];
+  if (CF_REGS) {
+#pragma unroll
+    for (int j = 0; j < (CF_REGS ? KC : 0); ++j) {
+      const int ci = 16 * j + 4 * q;
+      c_sc[j] = ld4(cf0 + ci);
+      c_sh[j] = ld4(cf0 + KP + ci);
+      c_dsc[j] = ld4(cf0 + 2 * KP + ci);
+      c_dsh[j] = ld4(cf0 + 3 * KP + ci);
+    }
+  }
   TilePos cur = ct.pos((long)blockIdx.x * 4 + wave), nxt = cur;
 #pragma unroll
   for (int jj = 0; jj < KCH; ++jj) request(cur, 0, jj);
@@ -193,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const f
 #pragma unroll
       for (int jj = 0; jj < KCH; ++jj) {
         const int ci = 16 * (h * KCH + jj) + 4 * q;
-        const float4 sc = ld4(cf + ci), sh = ld4(cf + KP + ci);
+        const float4 sc = CF_REGS ? c_sc[CF_REGS ? h * KCH + jj : 0] : ld4(cf + ci);
+        const float4 sh = CF_REGS ? c_sh[CF_REGS ? h * KCH + jj : 0] : ld4(cf + KP + ci);
         const float4 s00 = clamp4(fma4(r[jj][0], sc, sh), ilo, ihi), s01 = clamp4(fma4(r[jj][1], sc, sh), ilo, ihi);
         const float4 s10 = clamp4(fma4(r[jj][2], sc, sh), ilo, ihi), s11 = clamp4(fma4(r[jj][3], sc, sh), ilo, ihi);
         if (h + 1 < KH) request(cur, h + 1, jj);
@@ -206,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void pw_virt_fwd_kernel(LazySrc In, const f
         y[3] = fma4(s01, ld4(wt + 6 * KP + ci), y[3]);
         y[3] = fma4(s10, ld4(wt + 2 * KP + ci), y[3]);
         y[3] = fma4(s11, ld4(wt + ci), y[3]);
-        const float4 dsc = ld4(cf + 2 * KP + ci), dsh = ld4(cf + 3 * KP + ci);
+        const float4 dsc = CF_REGS ? c_dsc[CF_REGS ? h * KCH + jj : 0] : ld4(cf + 2 * KP + ci);
+        const float4 dsh = CF_REGS ? c_dsh[CF_REGS ? h * KCH + jj : 0] : ld4(cf + 3 * KP + ci);
         float4 in[4];
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
