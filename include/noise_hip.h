@@ -351,7 +351,7 @@ int noise_adamw_step(float* p, const float* g, float* m, float* v, long long* st
 /* dst = src (n floats, n % 4 == 0): 8 * n bytes of HBM traffic */
 int noise_bench_copy(const float* src, float* dst, long n, void* stream);
 /* back-to-back MFMA issue: kind 0 = v_mfma_f32_16x16x4_f32 (2048 flop per wave instruction), kind 1 =
- * v_mfma_f32_16x16x32_f16 (16384 flop); blocks x 4 waves x iters x 4 instructions; out: blocks * 256 floats */
+ * v_mfma_f32_16x16x32_f16 (16384 flop), kind 2 = v_mfma_f32_32x32x2_f32 (4096 flop); blocks x 4 waves x iters x 4 instructions; out: blocks * 256 floats */
 int noise_bench_mfma(int kind, float* out, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus

@@ -39,7 +39,8 @@ out["fill_GBs"] = round(4 * n / dt / 1e9, 1)
 del src, dst
 blocks, iters = 256 * 8, 4096                   # 8 workgroups of 4 waves per CU: 8 waves per SIMD
 buf = torch.empty(blocks * 256, device=dev)
-for kind, name, flop in ((0, "mfma_f32_16x16x4_TFLOPs", 2048), (1, "mfma_f16_16x16x32_TFLOPs", 16384)):
+for kind, name, flop in ((0, "mfma_f32_16x16x4_TFLOPs", 2048), (1, "mfma_f16_16x16x32_TFLOPs", 16384),
+                         (2, "mfma_f32_32x32x2_TFLOPs", 4096)):
     dt = timed(lambda: _lib.call("noise_bench_mfma", kind, ptr(buf), blocks, iters, _lib.stream()), reps=5)
     out[name] = round(blocks * 4 * iters * 4 * flop / dt / 1e12, 1)
 out["note"] = ("copy: float4 grid-stride kernel over 2 x 4 GiB; fill: torch fill_ of 4 GiB; mfma: 8 waves per SIMD, 4 independent "
