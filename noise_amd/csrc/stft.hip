@@ -25,7 +25,7 @@ constexpr int STFT_TF = 64;  // frames per workgroup
 // MODE 0: forward  -> log-magnitude, phase, per-clip max|log-magnitude|
 // MODE 1: adjoint of the iSTFT: sig = dL/d(wave_out); writes dL/d(log-magnitude)
 template <int MODE, int NT>
-__global__ __launch_bounds__(256) void stft_frames_kernel(
+__global__ __launch_bounds__(256, (NT <= 3 ? 3 : 1)) void stft_frames_kernel(
     const float* __restrict__ sig, const float* __restrict__ basisT, float* __restrict__ out0,
     float* __restrict__ out1, unsigned* __restrict__ absmax_bits, const float* __restrict__ wave_out,
     const float* __restrict__ wsum, const float* __restrict__ logmag, const float* __restrict__ phase,
