@@ -25,7 +25,7 @@ constexpr int STFT_TF = 64;  // frames per workgroup
 // MODE 0: forward  -> log-magnitude, phase, per-clip max|log-magnitude|
 // MODE 1: adjoint of the iSTFT: sig = dL/d(wave_out); writes dL/d(log-magnitude)
 template <int MODE, int NT>
-__global__ __launch_bounds__(256, (NT <= 3 ? 3 : 1)) void stft_frames_kernel(
+__global__ __launch_bounds__(256, (NT <= 3 ? 4 : 1)) void stft_frames_kernel(
     const float* __restrict__ sig, const float* __restrict__ basisT, float* __restrict__ out0,
     float* __restrict__ out1, unsigned* __restrict__ absmax_bits, const float* __restrict__ wave_out,
     const float* __restrict__ wsum, const float* __restrict__ logmag, const float* __restrict__ phase,
@@ -37,7 +37,11 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 3 : 1)) void stft_frames_kernel(
   const int t0 = blockIdx.x * STFT_TF;
   const int hop = d.hop, n_fft = d.n_fft, pitch = hop + 1;
   const int R = n_fft / hop;
-  const int nS = (STFT_TF - 1) * hop + n_fft;
+  // a tile of a short clip holds fewer than STFT_TF frames: only their samples are staged (the launcher sizes the LDS for
+  // the largest tile, so 0.5 s segments fit four workgroups per CU); the MFMA columns of the missing frames repeat the
+  // last staged frame and are dropped in the epilogue
+  const int nfr = min(STFT_TF, d.T - t0);
+  const int nS = (nfr - 1) * hop + n_fft;
   const int half = n_fft / 2;
 
   // ---- stage the samples of this tile (index in the padded signal = t0*hop + i)
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 3 : 1)) void stft_frames_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
+  const int nc0 = min(n, nfr - 1), nc1 = min(n + 32, nfr - 1);
   const float* bas = basisT + n;
   int rtc[NT];
 #pragma unroll
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 3 : 1)) void stft_frames_kernel(
 #pragma unroll 8
     for (int kq = 0; kq < hop; kq += 2) {
       const int kk = c * hop + kq + h;
-      const float b0 = lds[n * pitch + kk + c];
-      const float b1 = lds[(n + 32) * pitch + kk + c];
+      const float b0 = lds[nc0 * pitch + kk + c];
+      const float b1 = lds[nc1 * pitch + kk + c];
       const float* arow = bas + (size_t)kk * d.Rpad;
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
@@ -464,7 +469,7 @@ int launch_frames(const float* sig, const float* basisT, float* out0, float* out
                   StftDims d, hipStream_t st) {
   const int nRT = d.Rpad / 32;
   const int per_wave = (nRT + 3) / 4;
-  const int nS = (STFT_TF - 1) * d.hop + d.n_fft;
+  const int nS = ((d.T < STFT_TF ? d.T : STFT_TF) - 1) * d.hop + d.n_fft;   // samples of the largest tile
   const size_t smem = (size_t)(nS + nS / d.hop + 1) * sizeof(float);
   dim3 grid(noise_cdiv(d.T, STFT_TF), d.B);
   if (per_wave <= 3) {
