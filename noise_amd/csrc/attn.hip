@@ -740,8 +740,8 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
 //     O^T [d][query] += V^T P^T                  (4 MFMAs; MFMA k-step s takes key 4*q + s, i.e. the lane's own
 //                                                 register s, so P goes from one MFMA to the next without moving)
 template <int DK4>
-__global__ __launch_bounds__(256) void attn_core_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                                 float* __restrict__ ml, AttnDims d, int nsplit) {
+__global__ __launch_bounds__(1024) void attn_core_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                  float* __restrict__ ml, AttnDims d, int nsplit) {
   extern __shared__ float lds[];
   constexpr int DKP = DK4 * 4;
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
@@ -751,8 +751,9 @@ __global__ __launch_bounds__(256) void attn_core_fwd_mfma_kernel(const float* __
   float* ks = lds;                   // [n16][DKP], rows >= n zero
   float* vs = ks + n16 * DKP;        // [n16 + 1][DKP] (one spare row: lanes d >= DKP read past a row)
   const long base = (long)b * n;
+  const int nthr = blockDim.x, nw = nthr >> 6;
 #pragma unroll 4
-  for (int i = threadIdx.x; i < (n16 + 1) * DKP; i += 256) {   // clamped addresses, padding selected afterwards
+  for (int i = threadIdx.x; i < (n16 + 1) * DKP; i += nthr) {   // clamped addresses, padding selected afterwards
     const int j = i / DKP, c = i - j * DKP;
     const bool in = j < n && c < dk;
     const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : dk - 1);
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(256) void attn_core_fwd_mfma_kernel(const float* __
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   const float temp = sqrtf((float)dk);
-  for (int qt = split * 4 + wave; qt < ntile; qt += 4 * nsplit) {
+  for (int qt = split * nw + wave; qt < ntile; qt += nw * nsplit) {
     const int qi = qt * 16 + p;
     const bool valid = qi < n;
     const float* qrow = qkv + (base + (valid ? qi : n - 1)) * O + h * dk;
@@ -1267,15 +1268,17 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
     const int dk4 = (dk + 3) / 4, n16 = (n + 15) / 16 * 16;
     const size_t sm = sm_mfma;
     const long bh = (ntok / n) * heads;
+    // K and V in LDS bound the workgroups a CU holds; past 32 KB the waves have to come from inside the workgroup
+    const int threads = sm > 32 * 1024 ? 1024 : 256, nw = threads / 64;
     int nsplit = (int)(1024 / bh);
-    const int max_split = (n16 / 16 + 3) / 4;
+    const int max_split = (n16 / 16 + nw - 1) / nw;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     const dim3 grid((unsigned)(bh * nsplit));
 #define X(K4)                                                                                                      \
   if (dk4 == K4) {                                                                                                 \
     NOISE_ALLOW_LDS(attn_core_fwd_mfma_kernel<K4>, sm);                                                            \
-    hipLaunchKernelGGL(attn_core_fwd_mfma_kernel<K4>, grid, dim3(256), sm, (hipStream_t)stream, qkv, o, ml, d, nsplit); \
+    hipLaunchKernelGGL(attn_core_fwd_mfma_kernel<K4>, grid, dim3(threads), sm, (hipStream_t)stream, qkv, o, ml, d, nsplit); \
   }
     X(1) X(2) X(3) X(4)
 #undef X

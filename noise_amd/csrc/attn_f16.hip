@@ -21,7 +21,7 @@ struct Attn16Dims {
   int n, heads, dk, hd, n32, vp;   // n32 = n rounded up to the 64 keys of a step; vp = row pitch of V^T (halves)
 };
 
-__global__ __launch_bounds__(512) void attn_core_f16_kernel(const float* __restrict__ qkv, float* __restrict__ o, Attn16Dims d,
+__global__ __launch_bounds__(1024) void attn_core_f16_kernel(const float* __restrict__ qkv, float* __restrict__ o, Attn16Dims d,
                                                             int nsplit, int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* ks = reinterpret_cast<_Float16*>(lds_raw);   // [n32][16], rows >= n and columns >= d_k zero
@@ -142,7 +142,7 @@ NOISE_EXPORT int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, 
   const size_t smem = ((size_t)d.n32 * 16 + (size_t)16 * d.vp) * sizeof(_Float16);
   NOISE_REQUIRE(smem <= 158 * 1024, "noise_attn_core_fwd_f16: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
   const long bh = (ntok / n) * heads;
-  const int threads = smem > 48 * 1024 ? 512 : 256, nw = threads / 64;
+  const int threads = smem > 32 * 1024 ? 1024 : 256, nw = threads / 64;
   int nsplit = (int)(2048 / bh);
   const int max_split = ((n + 15) / 16 + nw - 1) / nw;
   if (nsplit > max_split) nsplit = max_split;
