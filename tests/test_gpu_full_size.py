@@ -115,3 +115,29 @@ def test_mixer_1024_rows_is_rowwise(dev):
                                           level[idx].contiguous())
         assert torch.equal(c1, c[idx]) and torch.equal(n1, n[idx]) and torch.equal(y1, y[idx])
         assert torch.equal(lv1, lv[idx])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_streaming_1024_streams_is_streamwise(dev, golden_dir, mode):
+    """The window driver (demo/src/worker.js:5-66) at the benchmark's 1024 concurrent streams: a stream's emitted
+    blocks inside the batch equal the blocks of the same stream driven in a batch of two (the small driver is the
+    one pinned against the oracle), over three hops, graph replay included."""
+    from noise_amd import StreamingDenoiser
+    m = build(320, 160, dev, golden_dir).eval()
+    with torch.no_grad():
+        m.model.vad.bias.fill_(3.0)               # keep the VAD gate (models.py:754) open
+    m.inference_dtype = mode
+    N, hops = 1024, 3
+    gen = torch.Generator().manual_seed(21)
+    audio = (torch.randn(N, hops * 3200, generator=gen) * 0.1).clamp(-1, 1).to(dev)
+    pick = [7, 1023]
+    big, small = StreamingDenoiser(m, N), StreamingDenoiser(m, len(pick))
+    heard = False
+    for h in range(hops):
+        block = audio[:, h * 3200:(h + 1) * 3200]
+        out_big = big.push_block(block.contiguous()).clone()
+        out_small = small.push_block(block[pick].contiguous()).clone()
+        assert out_big.shape == (N, 3200) and bool(torch.isfinite(out_big).all())
+        assert torch.equal(out_big[pick], out_small), float((out_big[pick] - out_small).abs().max())
+        heard = heard or float(out_big.abs().max()) > 1e-3
+    assert heard
