@@ -170,3 +170,26 @@ def test_checkpoint_round_trip(tmp_path):
     assert all(torch.equal(sd[k], sd2[k]) for k in sd)
     m3 = VADSpectralV2.load_from_checkpoint(path, max_frames=40, pad_value=-1)
     assert m3.hparams.pad_value == -1
+
+
+def test_product_path_has_no_cpu_stand_in(tmp_path):
+    """The CPU oracle is test infrastructure: nothing under noise_amd/ may name it, bench.py may only import it inside
+    its CPU-baseline leg, and importing the package without the built library must raise instead of degrading."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "noise_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{f} imports the oracle"
+    bench = open(os.path.join(root, "bench.py"), encoding="utf-8").read()
+    imports = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle\b", bench, re.M)]
+    start = bench.index("def cpu_baseline")
+    end = bench.index("\ndef ", start + 1)
+    assert imports and all(start < i < end for i in imports), "bench.py may use the oracle in cpu_baseline() only"
+    # a missing library is an ImportError that names the file, not a silent fallback
+    env = dict(os.environ, NOISE_HIP_LIB=str(tmp_path / "absent.so"), PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", "import noise_amd"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "absent.so is missing" in r.stderr and "no CPU fallback" in r.stderr
