@@ -38,8 +38,21 @@ __global__ __launch_bounds__(256) void copy_ticket_kernel(const v4f* __restrict_
   }
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void copy_variant_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, long n4) {
+__global__ __launch_bounds__(256) void copy_variant_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, long n4,
+                                                           int chunked) {
   constexpr int U = (MODE & 4) ? 4 : 1;
+  if (chunked) {   // every workgroup copies one contiguous share of the buffer, front to back
+    const long pieces = (n4 + 256 * U - 1) / (256 * U), per = (pieces + gridDim.x - 1) / gridDim.x;
+    const long p1 = min(pieces, (long)(blockIdx.x + 1) * per);
+    for (long pc = (long)blockIdx.x * per; pc < p1; ++pc) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = pc * 256 * U + 256 * u + threadIdx.x;
+        if (i < n4) dst[i] = src[i];
+      }
+    }
+    return;
+  }
   const long step = (MODE & 8) ? n4 : (long)gridDim.x * 256 * U;
   if (MODE & 16) {   // persistent and software-pipelined: the next pieces are requested before the current ones are stored
     long i0 = (long)blockIdx.x * 256 * U + threadIdx.x;
@@ -162,10 +175,12 @@ NOISE_EXPORT int noise_bench_copy(const float* src, float* dst, long n, void* st
     const char* grid_s = getenv("NOISE_COPY_GRID");   // workgroups of the persistent forms (default: 8 per CU)
     const long persistent = grid_s ? atol(grid_s) : noise_num_cus() * 8;
     NOISE_REQUIRE(persistent > 0 && persistent < (1l << 31), "noise_bench_copy: bad NOISE_COPY_GRID");
+    const int chunked = getenv("NOISE_COPY_CHUNKED") != nullptr;   // contiguous share per workgroup instead of a stride
     const dim3 grid((unsigned)((mode & 8) ? oneshot : persistent));
 #define X(M)                                                                                                            \
   if (mode == M)                                                                                                        \
-    hipLaunchKernelGGL(copy_variant_kernel<M>, grid, dim3(256), 0, (hipStream_t)stream, (const v4f*)src, (v4f*)dst, n4);
+    hipLaunchKernelGGL(copy_variant_kernel<M>, grid, dim3(256), 0, (hipStream_t)stream, (const v4f*)src, (v4f*)dst, n4, \
+                       chunked);
     X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
 #undef X
     NOISE_CHECK_LAUNCH("noise_bench_copy/variant");

@@ -40,10 +40,19 @@ os.environ.pop("NOISE_COPY_GRID")
 os.environ["NOISE_COPY_MODE"] = "8"
 dt = timed(lambda: _lib.call("noise_bench_copy", ptr(src), ptr(dst), n, _lib.stream()))
 print(f"one-shot (1 iteration, {n // 1024} workgroups) {8 * n / dt / 1e9:8.1f} GB/s")
-for batch in (8, 16, 32, 63):
+for batch in (16,):
     os.environ["NOISE_COPY_MODE"] = str(32 + batch)
     for grid in (1024, 2048):
         os.environ["NOISE_COPY_GRID"] = str(grid)
         dt = timed(lambda: _lib.call("noise_bench_copy", ptr(src), ptr(dst), n, _lib.stream()))
         assert torch.equal(src[:4096], dst[:4096]) and torch.equal(src[-4096:], dst[-4096:])
         print(f"ticket counter, {batch} x 4 KiB per ticket, grid {grid}: {8 * n / dt / 1e9:8.1f} GB/s")
+os.environ["NOISE_COPY_CHUNKED"] = "1"
+for mode in (0, 4):
+    os.environ["NOISE_COPY_MODE"] = str(mode)
+    for grid in (1024, 2048, 8192, 65536):
+        os.environ["NOISE_COPY_GRID"] = str(grid)
+        dt = timed(lambda: _lib.call("noise_bench_copy", ptr(src), ptr(dst), n, _lib.stream()))
+        assert torch.equal(src[:4096], dst[:4096]) and torch.equal(src[-4096:], dst[-4096:])
+        print(f"contiguous share per workgroup, mode {mode}, grid {grid}: {8 * n / dt / 1e9:8.1f} GB/s")
+os.environ.pop("NOISE_COPY_CHUNKED")
