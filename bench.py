@@ -13,6 +13,7 @@ rank processes its own 640 audio-seconds per step; the only exchange is one all-
 gradient buffer.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -274,12 +275,17 @@ def main():
                   file=sys.stderr)
     _lib.PROFILE = prof = []
     _lib.PROFILE_ONLY = None if args.all_events else {dom}
+    # The host enqueues a step in ~2 ms and only runs ahead of the GPU after the first timed steps: a generation-2
+    # garbage collection (tens of ms on torch's heap) in that window would idle the GPU and be charged to the kernels.
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out4 = model.train_step_fused(noisy, clean, opt, all_reduce)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     _lib.PROFILE = None
     _lib.PROFILE_ONLY = None
     loss = float(out4[0].item())
