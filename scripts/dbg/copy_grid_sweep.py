@@ -29,7 +29,7 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-for mode in (0,):
+for mode in (0, 4, 3):
     os.environ["NOISE_COPY_MODE"] = str(mode)
     for grid in (512, 1024, 2048, 4096, 8192, 16384, 65536, 262144):
         os.environ["NOISE_COPY_GRID"] = str(grid)
@@ -40,7 +40,7 @@ os.environ.pop("NOISE_COPY_GRID")
 os.environ["NOISE_COPY_MODE"] = "8"
 dt = timed(lambda: _lib.call("noise_bench_copy", ptr(src), ptr(dst), n, _lib.stream()))
 print(f"one-shot (1 iteration, {n // 1024} workgroups) {8 * n / dt / 1e9:8.1f} GB/s")
-for batch in (16,):
+for batch in (1, 2, 4, 8, 16, 32, 63):
     os.environ["NOISE_COPY_MODE"] = str(32 + batch)
     for grid in (1024, 2048):
         os.environ["NOISE_COPY_GRID"] = str(grid)
