@@ -508,7 +508,10 @@ int check_c(const char* who, int C) {
 
 }  // namespace
 
-NOISE_EXPORT int noise_conv_max_blocks(void) { return 2048; }
+NOISE_EXPORT int noise_conv_max_blocks(void) {
+  const int cap = walk_env("NOISE_WALK_CAP", 2048);   // diagnostic override (scripts/walk_sweep.py)
+  return cap > 2048 ? cap : 2048;
+}
 // The backward walkers hold one workgroup per CU (register-resident windows, coefficients and weight-gradient taps), so
 // more than 4 workgroups per CU only lengthens the slabs the finalize kernels fold.
 constexpr int BWD_MAX_BLOCKS = 1024;

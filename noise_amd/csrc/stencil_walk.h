@@ -554,6 +554,10 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
 }
 
 // Band layout: enough column slots to give every CU several workgroups, bands of at least 8 walked rows.
+inline int walk_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 inline void walk_plan(WalkDims& d, int walked_rows, int max_blocks, int& grid) {
   const int PPB = 256 / (d.C / 4);
   const long slots1 = (long)d.B * d.wown;
@@ -564,6 +568,17 @@ inline void walk_plan(WalkDims& d, int walked_rows, int max_blocks, int& grid) {
     const int max_nb = walked_rows / 8 > 1 ? walked_rows / 8 : 1;
     if (nb > max_nb) nb = max_nb;
   }
+  // Tall images: bands of 16 rows on at most 1024 workgroups.  Measured on 1280 x 81 x 33 tensors (scripts/walk_sweep.py):
+  // 4.5 -> 5.0 TB/s forward and 4.7 -> 5.0 TB/s backward for 32 channels, nothing lost for 16; bands of 4-8 rows or
+  // one workgroup per band lose 10-30 %, so the order in which the bands are visited is not what bounds these kernels.
+  if (walked_rows >= 64) {
+    nb = (walked_rows + 15) / 16;
+    if (max_blocks > 1024) max_blocks = 1024;
+  }
+  // NOISE_WALK_BH / NOISE_WALK_CAP (diagnostic, scripts/walk_sweep.py): band height and grid cap
+  const int ebh = walk_env("NOISE_WALK_BH", 0);
+  if (ebh > 0) nb = (walked_rows + ebh - 1) / ebh;
+  max_blocks = walk_env("NOISE_WALK_CAP", max_blocks);
   d.bh = (walked_rows + nb - 1) / nb;
   d.nb = (walked_rows + d.bh - 1) / d.bh;
   d.ngroups = (int)(((long)d.B * d.nb * d.wown + PPB - 1) / PPB);
