@@ -174,9 +174,8 @@ def stream_mix_augment_configs(device):
     rng = np.random.RandomState(0)
     N, B = 64, 256
     cl = (rng.randn(N, L) * 0.05).astype(np.float32)
-    ny = (cl + rng.randn(N, L).astype(np.float32) * 0.02).astype(np.float32)
     irs = [(rng.randn(16000) * np.exp(-np.arange(16000) / 3200.0)).astype(np.float32) for _ in range(8)]
-    pools = augment.AugmentPools(ny, cl, [(rng.randn(3 * L) * 0.05).astype(np.float32)], irs, device)
+    pools = augment.AugmentPools(cl, [(rng.randn(3 * L) * 0.05).astype(np.float32)], irs, device)
     t = augment.VADTrainAugment(pools, 8000, p=0.5, seed=0)
     items = t.draw([i % N for i in range(B)])
     for _ in range(3):

@@ -158,12 +158,15 @@ int noise_fir_apply(const float* xspec, int n_rows, long L, const int* ir_of_row
                     long y_stride, double* partial, void* stream);
 /* Gain, Shift, AddBackgroundNoise of every item (items: DEVICE array).  Items with ir < 0 leave through Cut,
  * PolarityInversion and Clip into out_noisy [n_items][length]; the others write the whole mixed clip to
- * mixed[ir_row][L].  out_clean [n_items][length] = Cut(Shift(clean)).  partial: n_items * noise_aug_chunks(L) * 3
- * doubles (kept for noise_aug_finish). */
+ * mixed[ir_row][L].  The input chain reads noisy_src, the target reads clean_src (the same pointer for
+ * VADNoiseDataset, data.py:541-562, whose two passes both start from the clean clip).  out_clean [n_items][length] =
+ * Clip(Cut(Shift(Gain(clean)))) with clean_gain != 0 (VADNoiseDataset: the frozen pass keeps Gain and Clip), else
+ * Cut(Shift(clean)) (NoiseDataset, data.py:410-427).  partial: n_items * noise_aug_chunks(L) * 3 doubles (kept for
+ * noise_aug_finish). */
 int noise_aug_chunks(long L);
 int noise_aug_mix(const noise_aug_item* items, int n_items, const float* noisy_src, const float* clean_src,
                   long src_stride, long L, const float* noise_pool, long noise_pool_len, double* partial, float* mixed,
-                  float* out_noisy, float* out_clean, int length, void* stream);
+                  float* out_noisy, float* out_clean, int length, int clean_gain, void* stream);
 /* data.py:194-208 after the convolution (RMS of the input restored, clip), then Cut, PolarityInversion, Clip, for the
  * n_rows convolved clips: reverb [n_rows][L] and rev_partial from noise_fir_apply, item_of_row [n_rows] their items. */
 int noise_aug_finish(const noise_aug_item* items, const int* item_of_row, int n_rows, const float* reverb, long L,

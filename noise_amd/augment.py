@@ -1,9 +1,11 @@
-"""Waveform augmentation of the VAD training data module on the GPU (train/data.py:439-461).
+"""Waveform augmentation of the VAD training data module on the GPU (train/data.py:439-461, 541-562).
 
-The reference builds every training pair on dataloader workers: the noisy clip goes through Gain -> Shift ->
-AddBackgroundNoise -> ImpulseResponse (p = 0.5) -> Cut -> PolarityInversion -> Clip, then the same parameters are
-frozen and the clean clip goes through the transforms named Cut, Shift, JustNoise and ToTensor only
-(train/data.py:410-427).  Here the source clips, the background noises and the impulse responses live in HBM
+The reference builds every training pair on dataloader workers from ONE clean clip (`VADNoiseDataset.__getitem__`,
+train/data.py:541-562): the network input is the clean clip through Gain -> Shift -> AddBackgroundNoise ->
+ImpulseResponse (p = 0.5) -> Cut -> PolarityInversion -> Clip, then the same parameters are frozen and the target is
+the clean clip through the transforms named Gain, Shift, Cut and Clip only, i.e. Clip(Cut(Shift(Gain(clean)))) with
+the gain of the input.  (The base `NoiseDataset`, train/data.py:410-427, reads separate noisy / clean files and keeps
+only Shift and Cut for the target: `AugmentPools(noisy=...)`.)  Here the source clips, the background noises and the impulse responses live in HBM
 (`AugmentPools`), the parameters of a batch are drawn on the host (`VADTrainAugment.draw`, distributions of
 train/data.py:441-458) and the arithmetic runs in the kernels of csrc/augment.hip through the C-ABI; the output is
 the reference's batch tuple `(noisy, clean)` of shape (B, 1, 1, length) on the device.
@@ -23,7 +25,7 @@ from ._lib import _I, _L, _P, ptr
 _lib.register({
     "noise_fir_spectra": [_P, _L, _I, _L, _I, _P, _P, _P, _P],
     "noise_fir_apply": [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P],
-    "noise_aug_mix": [_P, _I, _P, _P, _L, _L, _P, _L, _P, _P, _P, _P, _I, _P],
+    "noise_aug_mix": [_P, _I, _P, _P, _L, _L, _P, _L, _P, _P, _P, _P, _I, _I, _P],
     "noise_aug_finish": [_P, _P, _I, _P, _L, _P, _P, _P, _I, _P],
 })
 for _name in ("noise_fir_block", "noise_fir_blocks", "noise_fir_partials", "noise_aug_chunks"):
@@ -134,14 +136,19 @@ def impulse_response(samples, ir, device="cuda"):
 
 
 class AugmentPools:
-    """Device-resident sources: (noisy, clean) clip pairs of one length, background noises, impulse responses."""
+    """Device-resident sources: clean clips of one length, background noises, impulse responses.
 
-    def __init__(self, noisy, clean, noise_sounds, impulse_responses, device="cuda"):
+    `noisy` (optional, same shape as `clean`): separate already-noisy clips for the input chain, as the base
+    `NoiseDataset` reads them (train/data.py:410-427); without it the input chain starts from the clean clip
+    (`VADNoiseDataset`, train/data.py:541-562) and the target carries the input's gain and the final Clip."""
+
+    def __init__(self, clean, noise_sounds, impulse_responses, device="cuda", noisy=None):
         device = torch.device(device)
-        self.noisy = torch.as_tensor(noisy, dtype=torch.float32).to(device).contiguous()
         self.clean = torch.as_tensor(clean, dtype=torch.float32).to(device).contiguous()
-        if self.noisy.dim() != 2 or self.noisy.shape != self.clean.shape:
-            raise ValueError("noisy and clean must be (N, L) arrays of one shape")
+        self.paired = noisy is not None
+        self.noisy = torch.as_tensor(noisy, dtype=torch.float32).to(device).contiguous() if self.paired else self.clean
+        if self.clean.dim() != 2 or self.noisy.shape != self.clean.shape:
+            raise ValueError("clean (and noisy) must be (N, L) arrays of one shape")
         if len(noise_sounds) == 0:
             raise ValueError("at least one background noise is needed (data.py:75)")
         self.noise_lengths = np.array([len(s) for s in noise_sounds], dtype=np.int64)
@@ -152,7 +159,7 @@ class AugmentPools:
 
     @property
     def clip_length(self):
-        return self.noisy.shape[1]
+        return self.clean.shape[1]
 
 
 class VADTrainAugment:
@@ -225,7 +232,8 @@ class VADTrainAugment:
         clean = torch.empty(B, 1, 1, length, device=dev, dtype=torch.float32)
         st = _lib.stream()
         _lib.call("noise_aug_mix", ptr(d_items), B, ptr(pools.noisy), ptr(pools.clean), pools.noisy.stride(0), L,
-                  ptr(pools.noise), pools.noise.numel(), ptr(partial), ptr(mixed), ptr(noisy), ptr(clean), length, st,
+                  ptr(pools.noise), pools.noise.numel(), ptr(partial), ptr(mixed), ptr(noisy), ptr(clean), length,
+                  int(not pools.paired), st,
                   nbytes=4 * (2 * B * L + R * L + 2 * B * length))
         if R:
             ir_of_row = torch.from_numpy(items["ir"][with_ir].astype(np.int32)).to(dev)

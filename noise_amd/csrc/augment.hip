@@ -1,8 +1,10 @@
 // On-GPU waveform augmentation of the VAD training data module, gfx950.
 //
-// The chain train/data.py:439-461 applies to a (noisy, clean) pair of clips, parameters drawn once per pair:
-//   noisy: Gain -> Shift -> AddBackgroundNoise -> ImpulseResponse (p = 0.5) -> Cut -> PolarityInversion -> Clip
-//   clean: Shift -> Cut     (train/data.py:418-424: the second, frozen pass keeps only Cut, Shift, JustNoise, ToTensor)
+// The chain train/data.py:439-461, parameters drawn once per pair and frozen for the second pass:
+//   input : Gain -> Shift -> AddBackgroundNoise -> ImpulseResponse (p = 0.5) -> Cut -> PolarityInversion -> Clip
+//   target: VADNoiseDataset (train/data.py:541-562): both passes start from the CLEAN clip and the frozen pass keeps
+//           Gain, Shift, Cut and Clip -> target = Clip(Cut(Shift(Gain(clean)))), same gain as the input;
+//           NoiseDataset (train/data.py:410-427): separate noisy / clean files, the frozen pass keeps Shift and Cut only.
 // ImpulseResponse.apply (train/data.py:186-209) and process/process.py:69-75 (add_pyreverb) are a full FFT
 // convolution truncated to the input length; the former then matches the RMS of its input and clips.
 //
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(FNT, 2) void fir_apply_kernel(const c32* __restrict
 struct MixDims {
   long L, src_stride, pool_len;
   int nch, length;
+  int clean_gain;   // 1: target = Clip(Cut(Shift(Gain(clean)))) (VADNoiseDataset), 0: Cut(Shift(clean)) (NoiseDataset)
 };
 
 // Gain then Shift (vacated samples are zero, no rollover): sample i of the transformed clip.
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(256) void aug_mix_kernel(const noise_aug_item* __re
   for (int u = 0; u < AUG_CH / 256; ++u) {
     const long i = i0 + threadIdx.x + u * 256;
     const float s = aug_sample(x, d.L, it.shift, it.gain, i);
-    const float c = aug_sample(xc, d.L, it.shift, 1.f, i);
+    float c = aug_sample(xc, d.L, it.shift, d.clean_gain ? it.gain : 1.f, i);
+    if (d.clean_gain) c = fminf(fmaxf(c, -1.f), 1.f);
     const float nz = noise_pool[min(max(it.noise_off + (i % nlen), 0L), d.pool_len - 1)];
     const float y = s + nz * factor;
     const long j = i - it.cut;
@@ -402,12 +406,12 @@ NOISE_EXPORT int noise_fir_apply(const float* xspec, int n_rows, long L, const i
 
 NOISE_EXPORT int noise_aug_mix(const noise_aug_item* items, int n_items, const float* noisy_src, const float* clean_src,
                                long src_stride, long L, const float* noise_pool, long noise_pool_len, double* partial,
-                               float* mixed, float* out_noisy, float* out_clean, int length, void* stream) {
+                               float* mixed, float* out_noisy, float* out_clean, int length, int clean_gain, void* stream) {
   NOISE_REQUIRE(items && noisy_src && clean_src && noise_pool && partial && out_noisy && out_clean, "noise_aug_mix: null pointer");
   NOISE_REQUIRE(n_items > 0 && n_items <= 65535, "noise_aug_mix: n_items=%d outside 1..65535", n_items);
   NOISE_REQUIRE(L > 0 && src_stride >= L && noise_pool_len > 0 && length > 0 && length <= L,
                 "noise_aug_mix: L=%ld src_stride=%ld noise_pool_len=%ld length=%d", L, src_stride, noise_pool_len, length);
-  MixDims d{L, src_stride, noise_pool_len, noise_aug_chunks(L), length};
+  MixDims d{L, src_stride, noise_pool_len, noise_aug_chunks(L), length, clean_gain != 0};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(aug_stats_kernel, dim3(d.nch, n_items), dim3(256), 0, st, items, noisy_src, noise_pool, partial, d);
   hipLaunchKernelGGL(aug_mix_kernel, dim3(d.nch, n_items), dim3(256), 0, st, items, noisy_src, clean_src, noise_pool, partial,

@@ -239,6 +239,8 @@ class DenoiserPlan:
             keep = None     # eval / validation forwards never drop attention weights
         self.keep, self.seed = keep, int(seed)
         self.p_drop = ATTN_DROPOUT if training else 0.0
+        if training:
+            net.weights_changed()      # the finalize kernels update the BatchNorm running statistics in place
         r0 = self.enc[0][0]
         rows = ops.first_conv_fwd(logmag, absmax, r0.conv.weight, r0.y, self.slab if training else None, self.B, self.H,
                                   self.W, self.hp, self.wp, net.pad_value, r0.C, r0.stride)

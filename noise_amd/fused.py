@@ -199,9 +199,17 @@ class FusedDenoiser:
         self.pinned = 0
         self._wkey = None
 
+    def weights_key(self):
+        """Identity of the values the folded weight images were made from: autograd versions catch in-place tensor
+        writes, the net's update counter catches writes through raw device pointers (fused AdamW, running statistics
+        of a training forward, state_dict loads), the data pointer catches reallocation."""
+        net = self.net
+        return (net._weights_epoch,) + tuple(t._version for t in net.state_dict(keep_vars=True).values()) + \
+            (next(net.parameters()).data_ptr(),)
+
     def _weights(self):
         net = self.net
-        key = tuple(t._version for t in net.state_dict(keep_vars=True).values()) + (next(net.parameters()).data_ptr(),)
+        key = self.weights_key()
         if self._wkey != key:
             e, d = net.encoder, net.decoder
             self.head = HeadWeights(e[0], e[1].conv)

@@ -209,6 +209,18 @@ class VADMobileNetV2(_LightningModule):
         self.bottleneck_attention = TransformerEncoder(hidden, hidden, num_layers, nhead, self.d_k, self.d_k)
         self.vad = nn.Linear(hidden, 1)
         self._plans = {}
+        # Counts the updates of parameters / BatchNorm buffers made through raw device pointers (fused optimizer step,
+        # running statistics of a training forward, state_dict loads): such writes do not bump a tensor's `_version`,
+        # and the block-fused bf16 path keys its folded weight images on this counter as well.
+        self._weights_epoch = 0
+
+    def weights_changed(self):
+        self._weights_epoch += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.weights_changed()
+        return out
 
     def block_plan(self):
         return self._enc_plan, self._dec_plan
@@ -330,6 +342,11 @@ class VADSpectralV2(_LightningModule):
         self.attn_keep_mask = None     # optional explicit (B,heads,n,n) uint8 keep-mask for the next training step
         self.attn_seed = 0x5EED
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.model.weights_changed()
+        return out
+
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable(self):
         return [p for p in self.model.parameters()]
@@ -443,6 +460,8 @@ class VADSpectralV2(_LightningModule):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             static_out = self.forward(static_in)
+        # the bf16 path bakes its folded half-precision weight images (and their BatchNorm statistics) into the graph
+        wkey = plan.weights_key() if fused else None
         if self.model.plan(B, self.stft.cutoff, self.stft.num_frames(L), static_in.device, fused=fused) is not plan or \
                 self._flat_params is not flat or self.stft._derived is not derived:
             plan.pinned -= 1
@@ -457,6 +476,10 @@ class VADSpectralV2(_LightningModule):
                         flat.data_ptr() != model._trainable()[0].data_ptr():
                     raise RuntimeError("graphed_forward: the model's parameters or STFT bases were reallocated after "
                                        "the capture (.to(), load into new storage): capture again")
+                if wkey is not None and plan.weights_key() != wkey:
+                    raise RuntimeError("graphed_forward: parameters or BatchNorm statistics changed after the capture "
+                                       "(optimizer step, training forward, load_state_dict); the bf16 graph holds "
+                                       "folded copies of the old values: capture again")
                 static_in.copy_(waveforms)
                 graph.replay()
                 return static_out

@@ -33,6 +33,7 @@ class FusedAdamW:
         _lib.call("noise_adamw_step", ptr(flat), ptr(grads), ptr(self._m), ptr(self._v), ptr(self._step), flat.numel(),
                   self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale), _lib.stream(),
                   nbytes=28 * flat.numel())
+        self.model.model.weights_changed()     # the kernel wrote the parameters through a raw pointer
 
     def state_dict(self):
         self._state()

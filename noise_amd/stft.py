@@ -155,7 +155,11 @@ class STFT(torch.nn.Module):
             f2, i2 = fb[:, 0, :], ib[:, 0, :]
             sym = self.use_symmetry and is_symmetric(f2, self.n_fft) and is_symmetric(i2, self.n_fft)
             fft = None
-            if self.use_fft and fb.is_cuda and _lib.lib.noise_fft_supported(self.n_fft) and self.n_fft % self.hop_length == 0:
+            # the FFT entry points need an even hop that divides n_fft with fewer than 32 overlapping frames per sample
+            # (check_fft / noise_istft_fwd_fft in csrc/fft.hip); other hops stay on the dense-basis kernels
+            hop = self.hop_length
+            if self.use_fft and fb.is_cuda and _lib.lib.noise_fft_supported(self.n_fft) and self.n_fft % hop == 0 \
+                    and hop % 2 == 0 and self.n_fft // hop < 32:
                 fft = fft_tables(f2, i2, self.n_fft)
             self._derived = (key, sym, interleaved_transposed(f2, self.n_fft), interleaved_transposed(i2, self.n_fft),
                              folded(f2, self.n_fft) if sym else None, folded(i2, self.n_fft) if sym else None, fft)

@@ -2,8 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/ (and the smoke check); the product path never calls it.
 
-Follows, in the reference: train/data.py:439-461 (the chain and its order), :410-427 (the clean clip is transformed
-with frozen parameters and only by Cut, Shift, JustNoise, ToTensor), :30-57 (Cut), :186-209 (ImpulseResponse.apply),
+Follows, in the reference: train/data.py:439-461 (the chain and its order), :541-562 (VADNoiseDataset: input and
+target both start from the clean clip; the target is transformed with the frozen parameters and only by Gain, Shift,
+Cut, Clip), :410-427 (NoiseDataset: separate noisy file, target through Shift and Cut only), :30-57 (Cut), :186-209 (ImpulseResponse.apply),
 :119-157 (JustNoise.apply: the reference's own restatement of AddBackgroundNoise's scaling and tiling, which
 AddBackgroundNoise finishes with `samples + noise_sound`); process/process.py:69-75 (add_pyreverb).
 
@@ -82,9 +83,8 @@ def cut(samples, offset, length):
     return samples[offset: offset + length] if length > 0 else samples
 
 
-def vad_pair(noisy, clean, item, noise_pool, impulse_responses, length):
-    """One (noisy, clean) pair through data.py:439-461 with the parameters of `item` (fields of noise_aug_item)."""
-    x = gain(np.asarray(noisy, dtype=np.float32), item["gain"])
+def _input_chain(x, item, noise_pool, impulse_responses, length):
+    x = gain(np.asarray(x, dtype=np.float32), item["gain"])
     x = shift(x, item["shift"])
     if item["noise_len"] > 0:
         seg = noise_pool[int(item["noise_off"]): int(item["noise_off"]) + int(item["noise_len"])]
@@ -94,6 +94,21 @@ def vad_pair(noisy, clean, item, noise_pool, impulse_responses, length):
     x = cut(x, int(item["cut"]), length)
     if item["invert"]:
         x = -x
-    x = np.clip(x, -1.0, 1.0)
+    return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+def vad_pair(clean, item, noise_pool, impulse_responses, length):
+    """One (input, target) pair of VADNoiseDataset (data.py:541-562) with the parameters of `item` (fields of
+    noise_aug_item): input = the whole chain on the clean clip, target = Clip(Cut(Shift(Gain(clean))))."""
+    clean = np.asarray(clean, dtype=np.float32)
+    x = _input_chain(clean, item, noise_pool, impulse_responses, length)
+    c = np.clip(cut(shift(gain(clean, item["gain"]), item["shift"]), int(item["cut"]), length), -1.0, 1.0)
+    return x, c.astype(np.float32)
+
+
+def noise_pair(noisy, clean, item, noise_pool, impulse_responses, length):
+    """One pair of the base NoiseDataset (data.py:410-427): the input chain runs on the separate noisy clip, the frozen
+    pass keeps only Shift and Cut for the clean clip."""
+    x = _input_chain(noisy, item, noise_pool, impulse_responses, length)
     c = cut(shift(np.asarray(clean, dtype=np.float32), item["shift"]), int(item["cut"]), length)
-    return x.astype(np.float32), c.astype(np.float32)
+    return x, c.astype(np.float32)

@@ -131,7 +131,7 @@ def test_unsupported_configurations_say_so():
 
 def test_synthetic_datamodule_contract():
     from noise_amd import VADNoiseDataModule
-    dm = VADNoiseDataModule(data_dir="./data", sampling_rate=16000, length=8000, num_samples=64, num_workers=4,
+    dm = VADNoiseDataModule(data_dir=None, sampling_rate=16000, length=8000, num_samples=64, num_workers=4,
                             batch_size=16, p=0.3, device="cpu")
     dm.setup("fit")
     batches = list(dm.train_dataloader())

@@ -59,7 +59,7 @@ def test_convolution_ragged_lengths(L, n_ir):
     np.testing.assert_allclose(y[1][2:], x[1][:-2], atol=2e-6 * np.abs(x[1]).max() * 10)
 
 
-def _pools(aug, N=5, L=40000, seed=7):
+def _pools(aug, N=5, L=40000, seed=7, paired=False):
     rng = np.random.RandomState(seed)
     env = 0.5 * (1 - np.cos(2 * np.pi * 4 * np.arange(L) / 16000.0))
     clean = (rng.randn(N, L) * 0.1 * env).astype(np.float32)
@@ -71,7 +71,8 @@ def _pools(aug, N=5, L=40000, seed=7):
         h = rng.randn(n) * np.exp(-np.arange(n) / decay)
         h[0] = 1.0
         irs.append(h.astype(np.float32))
-    return aug.AugmentPools(noisy, clean, noises, irs), noisy, clean, noises, irs
+    pools = aug.AugmentPools(clean, noises, irs, noisy=noisy if paired else None)
+    return pools, noisy, clean, noises, irs
 
 
 @pytest.mark.gpu
@@ -101,8 +102,12 @@ def test_vad_chain_vs_oracle():
     assert got_noisy.shape == (len(rows), 1, 1, length) and got_clean.shape == got_noisy.shape
     gn, gc = got_noisy.cpu().numpy()[:, 0, 0], got_clean.cpu().numpy()[:, 0, 0]
     for n in range(len(rows)):
-        wn, wc = oa.vad_pair(noisy[items[n]["src"]], clean[items[n]["src"]], items[n], noise_pool, irs, length)
+        wn, wc = oa.vad_pair(clean[items[n]["src"]], items[n], noise_pool, irs, length)
         np.testing.assert_array_equal(gc[n], wc, err_msg=f"clean of item {n}")
+        # the target is the clean clip with the INPUT's gain, shifted, cut and clipped (data.py:541-562)
+        it = items[n]
+        direct = np.clip(oa.shift(clean[it["src"]] * np.float32(it["gain"]), it["shift"]), -1, 1)[it["cut"]: it["cut"] + length]
+        np.testing.assert_array_equal(gc[n], direct.astype(np.float32), err_msg=f"target of item {n}")
         err = np.abs(gn[n].astype(np.float64) - wn).max()
         assert err <= 1e-5, f"noisy of item {n}: max |diff| {err:.3e}"
         assert np.abs(gn[n]).max() <= 1.0
@@ -125,9 +130,16 @@ def test_drawn_batch_matches_oracle_and_is_reproducible():
     assert torch.equal(a_n, b_n) and torch.equal(a_c, b_c)
     noise_pool = np.concatenate(noises)
     for n in range(12):
-        wn, wc = oa.vad_pair(noisy[n], clean[n], items[n], noise_pool, irs, 8000)
+        wn, wc = oa.vad_pair(clean[n], items[n], noise_pool, irs, 8000)
         assert np.abs(a_n[n, 0, 0].cpu().numpy().astype(np.float64) - wn).max() <= 1e-5
         np.testing.assert_array_equal(a_c[n, 0, 0].cpu().numpy(), wc)
+    # the base NoiseDataset chain (data.py:410-427): separate noisy clips, target = Cut(Shift(clean)) without gain
+    pools2, noisy2, clean2, noises2, irs2 = _pools(aug, N=12, seed=11, paired=True)
+    p_n, p_c = aug.VADTrainAugment(pools2, 8000, p=0.5, seed=5).apply(items)
+    for n in range(12):
+        wn, wc = oa.noise_pair(noisy2[n], clean2[n], items[n], noise_pool, irs2, 8000)
+        assert np.abs(p_n[n, 0, 0].cpu().numpy().astype(np.float64) - wn).max() <= 1e-5
+        np.testing.assert_array_equal(p_c[n, 0, 0].cpu().numpy(), wc)
     # validation transforms cut the middle (data.py:39-41)
     v = aug.VADTrainAugment(pools, 8000, p=0.5, is_val=True, seed=5).draw(idx)
     assert (v["cut"] == (pools.clip_length - 8000) // 2).all()

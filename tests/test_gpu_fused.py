@@ -143,6 +143,43 @@ def test_fused_forward_vs_oracle(dev, golden_dir, tag, n_fft, hop, L, B, first_L
     np.testing.assert_allclose(m(wd).cpu().numpy(), out_ref.numpy(), atol=1e-4)
 
 
+def test_fused_weights_follow_training(dev, golden_dir):
+    """bf16 eval, one fused training step (parameters and BatchNorm statistics change through raw device pointers,
+    which bumps no tensor version), bf16 eval again: the folded weight images must be rebuilt.  The fp32 path reads
+    the live parameters, so the two paths have to agree after the step as they did before it; a captured bf16 graph
+    holds the old folded copies and has to refuse."""
+    from noise_amd.data import synth_batch
+    m = _build(320, 160, dev, golden_dir, True)
+    w = _clip(2, 8000, 5).to(dev)
+    m.inference_dtype = "bf16"
+    before = m(w).clone()
+    run = m.graphed_forward(w)
+    assert torch.equal(run(w), before)
+    opt = m.configure_optimizers()
+    opt.lr = 1e-2                      # a step large enough to move the output far beyond the bf16 tolerance
+    noisy, clean, _ = synth_batch(8, 8000, dev, seed=3)
+    m.train()
+    m.train_step_fused(noisy, clean, opt)
+    m.eval()
+    after = m(w).clone()
+    m.inference_dtype = "fp32"
+    ref = m(w)
+    print(f"bf16 after the step vs fp32: {_snr_db(after.cpu(), ref.cpu()):.1f} dB; stale output vs fp32: "
+          f"{_snr_db(before.cpu(), ref.cpu()):.1f} dB")
+    assert _snr_db(after.cpu(), ref.cpu()) >= 33.0, "bf16 forward ran on stale folded weights after a training step"
+    assert _snr_db(before.cpu(), ref.cpu()) < 25.0     # the step did change the output, so the check above is not vacuous
+    with pytest.raises(RuntimeError, match="capture again"):
+        run(w)
+    # a checkpoint loaded in place is seen as well
+    m.inference_dtype = "bf16"
+    sd = {k: (v * 0.5 if k.endswith("decoder.4.0.weight") else v.clone()) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.inference_dtype = "fp32"
+    ref2 = m(w).clone()
+    m.inference_dtype = "bf16"
+    assert _snr_db(m(w).cpu(), ref2.cpu()) >= 33.0
+
+
 @pytest.mark.parametrize("B,n,heads,dk", [(2, 55, 6, 10), (3, 704, 6, 10), (1, 1360, 6, 10), (2, 33, 4, 16), (2, 130, 8, 7),
                                           (1, 2000, 6, 10)])
 def test_attention_core_f16(dev, B, n, heads, dk):

@@ -201,6 +201,27 @@ def test_asymmetric_basis_takes_general_kernels(dev):
     assert STFT(100, 320, 160, 200, "hamming").to(dev)._bases()[0] is False
 
 
+@pytest.mark.parametrize("hop", [10, 5])
+def test_small_or_odd_hops_take_the_dense_kernels(dev, hop):
+    """The FFT kernels need an even hop with fewer than 32 overlapping frames per sample; other divisors of n_fft are
+    served by the dense-basis kernels instead of failing inside the FFT entry points."""
+    from oracle import spectral as osp
+    from noise_amd import STFT
+    st = STFT(400, 320, hop, 320, "hann").to(dev)
+    st.use_fft = True
+    assert st._fft() is None
+    w = (torch.randn(2, 1, 1, 320 * 4, generator=torch.Generator().manual_seed(hop)) * 0.1).clamp(-1, 1)
+    fwd, inv, wsum = osp.stft_buffers(400, 320, hop)
+    lm_ref, ph_ref = osp.stft_forward(w, fwd, 320, hop)
+    lm, ph = st.forward(w.to(dev))
+    X = torch.exp(lm[:, 0].cpu().double()) * torch.exp(1j * ph.cpu().double())
+    Xr = torch.exp(lm_ref[:, 0].double()) * torch.exp(1j * ph_ref.double())
+    floor = lm_ref[:, 0] > np.log(1e-3) + 1e-6
+    assert (X - Xr).abs()[floor].max().item() <= 1e-5 * Xr.abs().max().item()
+    rec = st.inverse(lm, ph).cpu()
+    np.testing.assert_allclose(rec.numpy(), osp.stft_inverse(lm_ref, ph_ref, inv, wsum, 320, hop).numpy(), atol=1e-5)
+
+
 def test_stft_rejects_bad_arguments(dev):
     from noise_amd import STFT
     st = STFT(100, 320, 160, 320, "hann")

@@ -41,6 +41,29 @@ def test_wav_round_trip_and_pairing(tmp_path):
     assert len(wavio.pair_files(str(tmp_path / "ds" / "train"))) == 2
 
 
+def test_rank_indices_pad_like_distributed_sampler():
+    from noise_amd.data import VADNoiseDataModule
+    for n, world in ((7, 2), (6, 4), (5, 8), (9, 3)):
+        per_rank = [VADNoiseDataModule(None, rank=r, world_size=world).rank_indices(n, True, 3) for r in range(world)]
+        assert len({len(p) for p in per_rank}) == 1 and len(per_rank[0]) == -(-n // world)      # equal batch counts
+        flat = np.stack(per_rank, 1).reshape(-1)                                                 # the padded order
+        assert sorted(set(flat.tolist())) == list(range(n))
+        np.testing.assert_array_equal(flat[n:], np.resize(flat[:n], len(flat) - n))              # padded with its own head
+    a = VADNoiseDataModule(None, rank=0, world_size=1)
+    assert not np.array_equal(a.rank_indices(50, True, 0), a.rank_indices(50, True, 1))
+    np.testing.assert_array_equal(a.rank_indices(5, False, 9), np.arange(5))
+
+
+def test_datamodule_refuses_an_empty_data_dir(tmp_path):
+    from noise_amd.data import VADNoiseDataModule
+    with pytest.raises(FileNotFoundError):
+        VADNoiseDataModule(str(tmp_path / "missing")).setup("fit")
+    os.makedirs(tmp_path / "ds" / "train" / "noisy")        # the reference's VAD layout has no noisy/: clean/ is what counts
+    with pytest.raises(FileNotFoundError):
+        VADNoiseDataModule(str(tmp_path / "ds")).setup("fit")
+    assert VADNoiseDataModule(None).setup("fit") is None    # synthetic audio only without a data_dir
+
+
 @pytest.mark.gpu
 def test_datamodule_batches_from_wav_files(tmp_path):
     import torch
@@ -48,29 +71,44 @@ def test_datamodule_batches_from_wav_files(tmp_path):
     from noise_amd.data import VADNoiseDataModule
     from oracle import augment as oa
     root = str(tmp_path / "ds")
-    _write_dataset(root)
-    seen = {}
+    _write_dataset(root, n=7)
+    import shutil
+    for split in ("train", "val"):
+        shutil.rmtree(os.path.join(root, split, "noisy"))   # VADNoiseDataModule.get_files reads clean/ only (data.py:486-488)
+    seen, counts = {}, []
     for rank in (0, 1):
-        dm = VADNoiseDataModule(root, length=8000, num_samples=6, batch_size=2, p=0.5, rank=rank, world_size=2)
+        dm = VADNoiseDataModule(root, length=8000, num_samples=7, batch_size=2, p=0.5, rank=rank, world_size=2)
         dm.setup("fit")
+        nb = 0
         for noisy, clean, names in dm.train_dataloader():
+            nb += 1
             assert noisy.shape == clean.shape == (len(names), 1, 1, 8000) and noisy.dtype == torch.float32
-            assert noisy.abs().max().item() <= 1.0
+            assert noisy.abs().max().item() <= 1.0 and clean.abs().max().item() <= 1.0
             for k, name in enumerate(names):
-                assert name not in seen
-                seen[name] = (noisy[k, 0, 0].cpu().numpy(), clean[k, 0, 0].cpu().numpy())
+                seen.setdefault(name, []).append((noisy[k, 0, 0].cpu().numpy(), clean[k, 0, 0].cpu().numpy()))
+        counts.append(nb)
+        assert dm.epoch == 1
         val = list(dm.val_dataloader())
-        assert sum(len(b[2]) for b in val) == 3
-    assert sorted(seen) == [f"fileid_{i}" for i in range(6)]
+        assert sum(len(b[2]) for b in val) == 4
+    assert counts[0] == counts[1] == 2                      # 7 clips on 2 ranks: padded to 8, two batches of 2 each
+    assert sorted(seen) == [f"fileid_{i}" for i in range(7)]
+    assert sorted(len(v) for v in seen.values()) == [1] * 6 + [2]
     # every pair equals the CPU chain with the parameters its index draws, whatever rank produced it
-    dm = VADNoiseDataModule(root, length=8000, num_samples=6, batch_size=6, p=0.5)
+    dm = VADNoiseDataModule(root, length=8000, num_samples=7, batch_size=7, p=0.5)
     dm.setup("fit")
     aug, names = dm._aug["train"]
-    items = aug.draw(list(range(6)), epoch=0)
+    items = aug.draw(list(range(7)), epoch=0)
     pools = aug.pools
     noise_pool = pools.noise.cpu().numpy()
     irs = [wavio.read_wav(os.path.join(root, "train", "ir", "room.wav"))]
     for i, name in enumerate(names):
-        wn, wc = oa.vad_pair(pools.noisy[i].cpu().numpy(), pools.clean[i].cpu().numpy(), items[i], noise_pool, irs, 8000)
-        assert np.abs(seen[name][0].astype(np.float64) - wn).max() <= 1e-5
-        np.testing.assert_array_equal(seen[name][1], wc)
+        wn, wc = oa.vad_pair(pools.clean[i].cpu().numpy(), items[i], noise_pool, irs, 8000)
+        for got_n, got_c in seen[name]:
+            assert np.abs(got_n.astype(np.float64) - wn).max() <= 1e-5
+            np.testing.assert_array_equal(got_c, wc)
+    # a clip shorter than `length` is skipped with a warning, not allowed to shorten the whole pool
+    wavio.write_wav(os.path.join(root, "train", "clean", "clean_fileid_99.wav"), np.zeros(100))
+    dm = VADNoiseDataModule(root, length=8000, num_samples=-1, batch_size=4)
+    with pytest.warns(UserWarning, match="shorter than length"):
+        dm.setup("fit")
+    assert len(dm._aug["train"][1]) == 7 and dm._aug["train"][0].pools.clip_length == 24000
