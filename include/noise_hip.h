@@ -177,6 +177,14 @@ int noise_aug_finish(const noise_aug_item* items, const int* item_of_row, int n_
 int noise_snr_mix(const double* clean, const double* noise, const int* snr, const int* level_draw,
                   double* clean_out, double* noise_out, double* noisy_out, int* level_out,
                   int n_utt, long L, double target_level, double clipping_threshold, void* stream);
+/* the same mix for the generation loop of process/process.py:240-256, which asks is_clipped (audiolib.py:18-19) of all
+ * three signals right after mixing: peaks_out [U][4] (optional) = max |clean_out|, max |noise_out|, max |noisy_out|,
+ * sum of noisy_out (a checksum); noisy_f32 [U][L] (optional) = float32 copy of noisy_out, the input of the STFT
+ * features */
+int noise_snr_mix_peaks(const double* clean, const double* noise, const int* snr, const int* level_draw,
+                        double* clean_out, double* noise_out, double* noisy_out, int* level_out, double* peaks_out,
+                        float* noisy_f32, int n_utt, long L, double target_level, double clipping_threshold,
+                        void* stream);
 int noise_activity(const double* audio, double* perc_active, int n_utt, long L, int fs,
                    double energy_thresh, double target_level, void* stream);
 
@@ -221,6 +229,10 @@ int noise_last_convT_bwd(const float* d_enh, const float* enh, const float* absm
  * dst [B][Hd][Wd][C] = src [B][Hs][Ws][C] at rows oy.., columns ox.. (raw values; the lazy coefficients carry over) */
 int noise_crop_nhwc(const float* src, float* dst, int B, int Hs, int Ws, int C, int oy, int ox, int Hd, int Wd,
                     void* stream);
+/* its adjoint (autograd of the slice at models.py:608 in a training step): g_src [B][Hs][Ws][C] = g_dst inside the
+ * window (which ends at the last row and column), zero on the rows / columns that were cut off */
+int noise_crop_nhwc_bwd(const float* g_dst, float* g_src, int B, int Hs, int Ws, int C, int oy, int ox, int Hd, int Wd,
+                        void* stream);
 /* pointwise convs (models.py:371-381, :395-396) as fp32 MFMA products: out [npix][N] = a [npix][K] x W[N][K]^T */
 int noise_pw_fwd(const float* a_y, const float* a_coef, int a_relu6, const float* b_y, const float* b_coef,
                  int b_relu6, const float* w, float* out, float* stats_slab, int* slab_rows, long npix, int K, int N,

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "noise_istft_bwd_fft": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "noise_fft_supported": [_I],
     "noise_snr_mix": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _D, _D, _P],
+    "noise_snr_mix_peaks": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _D, _D, _P],
     "noise_activity": [_P, _P, _I, _L, _I, _D, _D, _P],
 }
 

@@ -41,8 +41,8 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 __global__ __launch_bounds__(MIX_THREADS) void snr_mix_kernel(
     const double* __restrict__ clean, const double* __restrict__ noise, const int* __restrict__ snr,
     const int* __restrict__ level_draw, double* __restrict__ clean_out, double* __restrict__ noise_out,
-    double* __restrict__ noisy_out, int* __restrict__ level_out, long L, double target_level,
-    double clipping_threshold) {
+    double* __restrict__ noisy_out, int* __restrict__ level_out, double* __restrict__ peaks_out,
+    float* __restrict__ noisy_f32, long L, double target_level, double clipping_threshold) {
   __shared__ double red[MIX_THREADS / 64];
   const long u = blockIdx.x;
   const double* c = clean + u * L;
@@ -80,29 +80,57 @@ __global__ __launch_bounds__(MIX_THREADS) void snr_mix_kernel(
   const double scn = pow(10.0, (double)level / 20.0) / (rmsnoisy + MIX_EPS);
 
   // ---- pass 2: write at the drawn level (same operation order as the reference), track the peak
-  double my = 0;
+  // The peaks of the three outputs (what is_clipped, audiolib.py:18-19, looks at afterwards) and a float32 copy of the
+  // mix (the STFT features' input) come out of the same pass; both are optional.
+  double my = 0, pc = 0, pn = 0, sy = 0;
   for (long i = tid; i < L; i += MIX_THREADS) {
     const double a = (c[i] / kc) * sc;
     const double b = ((n[i] / kn) * sn) * noisescalar;
     const double y = (a + b) * scn;
-    clean_out[u * L + i] = a * scn;
-    noise_out[u * L + i] = b * scn;
+    const double ao = a * scn, bo = b * scn;
+    clean_out[u * L + i] = ao;
+    noise_out[u * L + i] = bo;
     noisy_out[u * L + i] = y;
     my = fmax(my, fabs(y));
+    pc = fmax(pc, fabs(ao));
+    pn = fmax(pn, fabs(bo));
+    sy += y;
   }
   my = block_max(my, red);
+  if (peaks_out) {
+    pc = block_max(pc, red);
+    pn = block_max(pn, red);
+    sy = block_sum(sy, red);
+  }
 
   // ---- pass 3 (only if the mix clips): renormalise all three signals by the peak
-  if (my > clipping_threshold) {
-    const double peak = my / (clipping_threshold - MIX_EPS);
+  const bool clips = my > clipping_threshold;
+  const double peak = clips ? my / (clipping_threshold - MIX_EPS) : 1.0;
+  if (clips) {
+    sy = 0;
     for (long i = tid; i < L; i += MIX_THREADS) {
       clean_out[u * L + i] = clean_out[u * L + i] / peak;
       noise_out[u * L + i] = noise_out[u * L + i] / peak;
-      noisy_out[u * L + i] = noisy_out[u * L + i] / peak;
+      const double y = noisy_out[u * L + i] / peak;
+      noisy_out[u * L + i] = y;
+      sy += y;
+      if (noisy_f32) noisy_f32[u * L + i] = (float)y;
     }
+    if (peaks_out) sy = block_sum(sy, red);
     level = (int)(20.0 * log10(scn / peak * (rmsnoisy + MIX_EPS)));
+  } else if (noisy_f32) {
+    // every thread re-reads the elements it wrote itself in pass 2
+    for (long i = tid; i < L; i += MIX_THREADS) noisy_f32[u * L + i] = (float)noisy_out[u * L + i];
   }
-  if (tid == 0) level_out[u] = level;
+  if (tid == 0) {
+    level_out[u] = level;
+    if (peaks_out) {   // division by the peak is monotonic: the largest element stays the largest
+      peaks_out[4 * u + 0] = clips ? pc / peak : pc;
+      peaks_out[4 * u + 1] = clips ? pn / peak : pn;
+      peaks_out[4 * u + 2] = clips ? my / peak : my;
+      peaks_out[4 * u + 3] = sy;   // sum of the mix: a checksum of the utterance (fixed summation order)
+    }
+  }
 }
 
 constexpr int ACT_THREADS = 256;
@@ -155,18 +183,29 @@ __global__ __launch_bounds__(ACT_THREADS) void activity_kernel(const double* __r
 
 }  // namespace
 
-NOISE_EXPORT int noise_snr_mix(const double* clean, const double* noise, const int* snr, const int* level_draw,
-                               double* clean_out, double* noise_out, double* noisy_out, int* level_out,
-                               int n_utt, long L, double target_level, double clipping_threshold, void* stream) {
+// peaks_out (optional): [n_utt][4] = max |clean_out|, max |noise_out|, max |noisy_out|, sum noisy_out per utterance;
+// noisy_f32 (optional): [n_utt][L] float32 copy of noisy_out.
+NOISE_EXPORT int noise_snr_mix_peaks(const double* clean, const double* noise, const int* snr, const int* level_draw,
+                                     double* clean_out, double* noise_out, double* noisy_out, int* level_out,
+                                     double* peaks_out, float* noisy_f32, int n_utt, long L, double target_level,
+                                     double clipping_threshold, void* stream) {
   NOISE_REQUIRE(n_utt >= 0 && L >= 0, "noise_snr_mix: negative size");
   if (n_utt == 0) return 0;
   NOISE_REQUIRE(L > 0, "noise_snr_mix: empty utterance");
   NOISE_REQUIRE(clean && noise && snr && level_draw && clean_out && noise_out && noisy_out && level_out,
                 "noise_snr_mix: null pointer");
   hipLaunchKernelGGL(snr_mix_kernel, dim3(n_utt), dim3(MIX_THREADS), 0, (hipStream_t)stream, clean, noise, snr,
-                     level_draw, clean_out, noise_out, noisy_out, level_out, L, target_level, clipping_threshold);
+                     level_draw, clean_out, noise_out, noisy_out, level_out, peaks_out, noisy_f32, L, target_level,
+                     clipping_threshold);
   NOISE_CHECK_LAUNCH("noise_snr_mix");
   return 0;
+}
+
+NOISE_EXPORT int noise_snr_mix(const double* clean, const double* noise, const int* snr, const int* level_draw,
+                               double* clean_out, double* noise_out, double* noisy_out, int* level_out,
+                               int n_utt, long L, double target_level, double clipping_threshold, void* stream) {
+  return noise_snr_mix_peaks(clean, noise, snr, level_draw, clean_out, noise_out, noisy_out, level_out, nullptr, nullptr,
+                             n_utt, L, target_level, clipping_threshold, stream);
 }
 
 NOISE_EXPORT int noise_activity(const double* audio, double* perc_active, int n_utt, long L, int fs,

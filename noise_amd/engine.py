@@ -191,11 +191,13 @@ class DenoiserPlan:
     def ensure_backward_buffers(self):
         if self.bwd_ready:
             return
-        if self.crops:
-            # training steps run on 8000-sample segments, whose padded geometry never crops a skip tensor
-            raise NotImplementedError("backward through cropped skip connections is not scheduled: call "
-                                      "model.reset_padding() so that the padding is searched for this input size")
         f32 = dict(device=self.device, dtype=torch.float32)
+        # a cropped skip (train/models.py:608 with a padding searched for another length): the gradient of the window
+        # goes back to the encoder tensor zero-padded to its full size
+        self.crop_grads = {}
+        for i, (win, oy, ox) in self.crops.items():
+            skip = self.enc[len(self.enc) - 1 - i][-1]
+            self.crop_grads[i] = torch.empty(skip.B, skip.Ho, skip.Wo, skip.C, **f32)
         for r in self.recs:
             if r.kind != "first":
                 r.g_in = torch.empty(r.B, r.Hi, r.Wi, r.Cin, **f32)
@@ -325,8 +327,16 @@ class DenoiserPlan:
         by_y = {id(r.y): r for r in self.recs if r.y is not None}
         pending_skip = {}      # id(rec) -> gradient w.r.t. that rec's activation coming from a decoder skip add
 
+        # cropped copies of skip tensors stand for the encoder layer they were cut from
+        crop_of = {id(win): (self.enc[len(self.enc) - 1 - i][-1], self.crop_grads[i], oy, ox)
+                   for i, (win, oy, ox) in self.crops.items()}
+
         def producer(src):
-            return by_y.get(id(src[0])) if src is not None else None
+            if src is None:
+                return None
+            if id(src[0]) in crop_of:
+                return crop_of[id(src[0])][0]
+            return by_y.get(id(src[0]))
 
         def epilogue_for(pa):
             if pa is None:
@@ -342,7 +352,11 @@ class DenoiserPlan:
             if pa is not None:
                 pa.dz = r.g_in
             if pb is not None:
-                pending_skip[id(pb)] = r.g_in
+                g = r.g_in
+                if r.src_b is not None and id(r.src_b[0]) in crop_of:
+                    _, g, oy, ox = crop_of[id(r.src_b[0])]
+                    ops.crop_nhwc_bwd(r.g_in, g, oy, ox)
+                pending_skip[id(pb)] = g
 
         # ---- last layer
         last = self.dec[-1][0]

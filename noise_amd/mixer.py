@@ -12,9 +12,11 @@ import torch
 from . import _lib
 
 
-def mix_batch(clean, noise, snr, level, target_level=-25.0, clipping_threshold=0.99):
+def mix_batch(clean, noise, snr, level, target_level=-25.0, clipping_threshold=0.99, with_peaks=False):
     """clean, noise: (U, L) float64 CUDA tensors; snr, level: (U,) int32 CUDA tensors.
-    Returns (clean_out, noise_out, noisy_out, level_out)."""
+    Returns (clean_out, noise_out, noisy_out, level_out); with_peaks adds (peaks, noisy_f32): per utterance the (U, 4)
+    values max|clean_out|, max|noise_out|, max|noisy_out| (what `is_clipped`, audiolib.py:18-19, decides on) and the sum
+    of the mix (a checksum), and a float32 copy of the mix, all written by the mixing pass itself."""
     _lib.require_cuda(clean, noise, snr, level)
     assert clean.dtype == torch.float64 and noise.dtype == torch.float64
     assert clean.shape == noise.shape and clean.dim() == 2
@@ -26,10 +28,12 @@ def mix_batch(clean, noise, snr, level, target_level=-25.0, clipping_threshold=0
     n = torch.empty_like(clean)
     y = torch.empty_like(clean)
     lv = torch.empty(U, dtype=torch.int32, device=clean.device)
-    _lib.call("noise_snr_mix", _lib.ptr(clean), _lib.ptr(noise), _lib.ptr(snr), _lib.ptr(level), _lib.ptr(c),
-              _lib.ptr(n), _lib.ptr(y), _lib.ptr(lv), U, L, float(target_level), float(clipping_threshold),
-              _lib.stream())
-    return c, n, y, lv
+    peaks = torch.empty(U, 4, dtype=torch.float64, device=clean.device) if with_peaks else None
+    y32 = torch.empty(U, L, dtype=torch.float32, device=clean.device) if with_peaks else None
+    _lib.call("noise_snr_mix_peaks", _lib.ptr(clean), _lib.ptr(noise), _lib.ptr(snr), _lib.ptr(level), _lib.ptr(c),
+              _lib.ptr(n), _lib.ptr(y), _lib.ptr(lv), _lib.ptr(peaks), _lib.ptr(y32), U, L, float(target_level),
+              float(clipping_threshold), _lib.stream(), nbytes=U * L * (56 + (4 if with_peaks else 0)))
+    return (c, n, y, lv, peaks, y32) if with_peaks else (c, n, y, lv)
 
 
 def activity_batch(audio, fs=16000, energy_thresh=0.13, target_level=-25.0):

@@ -34,6 +34,7 @@ _lib.register({
     "noise_pw_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_bn_bwd_finalize": [_P, _I, _I, _P, _P, _P, _P, _P, _L, _I, _P],
     "noise_crop_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "noise_crop_nhwc_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 })
 _lib.lib.noise_conv_max_blocks.restype = ctypes.c_int
 _lib.lib.noise_pw_wgrad_max_blocks.restype = ctypes.c_int
@@ -74,6 +75,14 @@ def crop_nhwc(src, dst, oy, ox):
     _, Hd, Wd, _ = dst.shape
     _lib.call("noise_crop_nhwc", ptr(src), ptr(dst), B, Hs, Ws, C, oy, ox, Hd, Wd, _lib.stream(),
               nbytes=8 * dst.numel())
+
+
+def crop_nhwc_bwd(g_dst, g_src, oy, ox):
+    """g_src (B,Hs,Ws,C) = g_dst (B,Hd,Wd,C) placed at rows oy.., columns ox.., zero elsewhere."""
+    B, Hs, Ws, C = g_src.shape
+    _, Hd, Wd, _ = g_dst.shape
+    _lib.call("noise_crop_nhwc_bwd", ptr(g_dst), ptr(g_src), B, Hs, Ws, C, oy, ox, Hd, Wd, _lib.stream(),
+              nbytes=4 * (g_dst.numel() + g_src.numel()))
 
 
 def dw3x3_fwd(a, b, w, out, slab, transposed, B, Hi, Wi, C, stride):

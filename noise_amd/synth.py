@@ -43,6 +43,7 @@ def generate_shard(n_files, rank=0, world=1, length=160000, seed=0, block=256, p
     device = torch.device(device)
     n_blocks = -(-n_files // block)
     stats = dict(files=0, kept=0, clipped=0, audio_seconds=0.0, blocks=[], checksums={})
+    kept_counts, checksums = [], []
     for b in range(rank, n_blocks, world):          # block b belongs to rank b % world: no exchange between ranks
         first = b * block
         n = min(block, n_files - first)
@@ -51,22 +52,21 @@ def generate_shard(n_files, rank=0, world=1, length=160000, seed=0, block=256, p
                             dtype=torch.int32)
         level = torch.randint(params["target_level_lower"], params["target_level_upper"], (n,), generator=g,
                               device=device, dtype=torch.int32)
-        c, nz, y, lv = mixer.mix_batch(clean, noise, snr, level)
-        # process.py:246-253 (is_clipped, audiolib.py:18-19): a file with any sample above the threshold is dropped
-        peak = torch.maximum(torch.maximum(c.abs().amax(1), nz.abs().amax(1)), y.abs().amax(1))
-        kept = peak <= 0.99
-        feats = []
-        if stfts:
-            y32 = y.to(torch.float32).view(n, 1, 1, length)
-            feats = [st.forward(y32) for st in stfts]
+        # process.py:246-253 (is_clipped, audiolib.py:18-19): a file with any sample above the threshold is dropped.
+        # The peaks of the three signals, the checksum and the float32 mix the STFT reads leave the mixing kernel itself.
+        c, nz, y, lv, peaks, y32 = mixer.mix_batch(clean, noise, snr, level, with_peaks=True)
+        kept = peaks[:, :3].amax(1) <= 0.99
+        feats = [st.forward(y32.view(n, 1, 1, length)) for st in stfts]
         out = dict(clean=c, noise=nz, noisy=y, level=lv, snr=snr, kept=kept, features=feats)
         if sink is not None:
             sink(b, first, out)
-        k = int(kept.sum().item())
+        kept_counts.append(kept.sum())
+        checksums.append(peaks[:, 3].sum())
         stats["files"] += n
-        stats["kept"] += k
-        stats["clipped"] += n - k
         stats["audio_seconds"] += n * length / 16000.0
         stats["blocks"].append(b)
-        stats["checksums"][b] = float(y.sum().item())
+    if stats["blocks"]:      # one host synchronisation per shard, not one per block
+        k = int(torch.stack(kept_counts).sum().item())
+        stats["kept"], stats["clipped"] = k, stats["files"] - k
+        stats["checksums"] = dict(zip(stats["blocks"], torch.stack(checksums).cpu().tolist()))
     return stats

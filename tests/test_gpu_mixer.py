@@ -60,6 +60,15 @@ def test_mixer_batch_vs_oracle(dev):
         np.testing.assert_allclose((c[u] + n[u]).cpu().numpy(), y[u].cpu().numpy(), rtol=0, atol=1e-15)
     assert took_branch
     assert float(y[3].abs().max().item()) <= 0.99
+    # the peaks and the float32 mix written by the mixing pass itself equal what separate passes would compute
+    c2, n2, y2, lv2, peaks, y32 = mixer.mix_batch(torch.from_numpy(clean).to(dev), torch.from_numpy(noise).to(dev),
+                                                  torch.from_numpy(snr).to(dev), torch.from_numpy(level).to(dev),
+                                                  with_peaks=True)
+    assert torch.equal(c2, c) and torch.equal(n2, n) and torch.equal(y2, y) and torch.equal(lv2, lv)
+    want = torch.stack([c.abs().amax(1), n.abs().amax(1), y.abs().amax(1)], 1)
+    assert torch.equal(peaks[:, :3], want)
+    np.testing.assert_allclose(peaks[:, 3].cpu().numpy(), y.sum(1).cpu().numpy(), rtol=1e-11, atol=1e-12)
+    assert torch.equal(y32, y.to(torch.float32))
 
 
 def test_mixer_drop_in_signature(dev):

@@ -250,7 +250,7 @@ def test_train_step_golden_autograd(dev, golden_dir, fixture):
     assert "val_loss" in m.logged_metrics
 
 
-def _oracle_grads(sd, noisy, clean, keep, dtype):
+def _oracle_grads(sd, noisy, clean, keep, dtype, padding=None, hop=160):
     from oracle import spectral as osp
     cast = (lambda v: v.to(dtype) if v.is_floating_point() else v)
     sdc = {k: cast(v) for k, v in sd.items()}
@@ -258,11 +258,52 @@ def _oracle_grads(sd, noisy, clean, keep, dtype):
               not ("running" in k or k.startswith("stft."))}
     full = dict(sdc)
     full.update(params)
-    bufs = tuple(b.to(dtype) for b in osp.stft_buffers(1200, 320, 160))
-    loss, _ = osp.shared_step(noisy.to(dtype), clean.to(dtype), full, bufs, 320, 160, training=True, new_stats={},
-                              attn_keep=keep)
+    bufs = tuple(b.to(dtype) for b in osp.stft_buffers(1200, 320, hop))
+    loss, _ = osp.shared_step(noisy.to(dtype), clean.to(dtype), full, bufs, 320, hop, training=True, new_stats={},
+                              attn_keep=keep, padding=padding)
     loss.backward()
     return loss.item(), {k: v.grad.double().numpy() for k, v in params.items()}
+
+
+def test_train_step_through_cropped_skips(dev, golden_dir):
+    """The reference searches its padding on the first forward and keeps it (models.py:585-586, 628-639).  With the
+    reference's hop of 160 every padding that lets an 8000-sample segment through (14 or 15 columns) leaves the skips
+    uncropped; with hop 80 a model whose first input had 99 frames (W_padding 14) trains on segments of 101 frames whose
+    full-resolution encoder outputs (58 columns) are one column wider than the decoder tensors coming back up (57), so
+    `x + skip[..., -h:, -w:]` (models.py:608) crops and the gradient of each cropped skip is zero on the cut column."""
+    m = build(320, 80, dev, golden_dir).eval()
+    with torch.no_grad():
+        m.model.decoder[-1][0].weight.mul_(0.02)
+        m.model.decoder[-1][0].bias.zero_()
+        m(torch.zeros(1, 1, 1, 98 * 80, device=dev))
+    padding = (m.model.H_padding, m.model.W_padding)
+    assert padding == (0, 14)
+    m.train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    B = 5
+    gen = torch.Generator().manual_seed(77)
+    clean = (torch.randn(B, 1, 1, 8000, generator=gen) * 0.05).clamp(-1, 1)
+    noisy = (clean + 0.03 * torch.randn(B, 1, 1, 8000, generator=gen)).clamp(-1, 1)
+    n_tok = 11 * 8                     # 161 x (101 + 14) -> 81x58 -> 41x29 -> 21x15 -> 11x8
+    keep = torch.rand(B, 6, n_tok, n_tok, generator=gen) > 0.1
+    loss32, g32 = _oracle_grads(sd, noisy, clean, keep, torch.float32, padding, hop=80)
+    loss64, g64 = _oracle_grads(sd, noisy, clean, keep, torch.float64, padding, hop=80)
+    m.attn_keep_mask = keep.to(torch.uint8).to(dev).contiguous()
+    out = m.training_step((noisy.to(dev), clean.to(dev), [""] * B), 0)
+    out.backward()
+    plan = m.model.plan(B, 161, 101, dev)
+    assert sorted(plan.crops) == [3, 4] and all(ox == 1 and oy == 0 for _, oy, ox in plan.crops.values())
+    np.testing.assert_allclose(out.item(), loss64, rtol=1e-4)
+    worst = ("", 0.0, 0.0)
+    for k, p in m.named_parameters():
+        ref = g64[k]
+        scale = max(np.abs(ref).max(), 1e-4)
+        e_gpu = np.abs(p.grad.cpu().double().numpy() - ref).max() / scale
+        e_cpu = np.abs(g32[k] - ref).max() / scale
+        allowed = max(2e-3, 2.0 * e_cpu)
+        if e_gpu / allowed > worst[1]:
+            worst = (k, e_gpu / allowed, e_gpu)
+    assert worst[1] < 1.0, worst
 
 
 @pytest.mark.parametrize("B,tame", [(1, True), (7, True), (33, True), (7, False)])
