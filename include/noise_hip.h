@@ -67,6 +67,11 @@ int noise_istft_bwd_sym(const float* d_wave, const float* wave_out, const float*
 int noise_fft_supported(int n_fft);
 int noise_stft_fwd_fft(const float* wave, const float* window, const float* tw1, const float* tw2, float* logmag,
                        float* phase, float* absmax, int B, int L, int n_fft, int hop, int fast_math, void* stream);
+/* noise_stft_fwd_fft with the per-clip normaliser absmax (models.py:614-620) evaluated in the accumulation order of
+ * noise_stft_fwd, i.e. of the reference's conv1d (models.py:465-467): the bins that can attain the max are recomputed as
+ * dense k-ordered dot products against basisT (layout of noise_stft_fwd).  The network input of the training step. */
+int noise_stft_fwd_fft_ref(const float* wave, const float* window, const float* tw1, const float* tw2, const float* basisT,
+                           float* logmag, float* phase, float* absmax, int B, int L, int n_fft, int hop, void* stream);
 int noise_istft_fwd_fft(const float* logmag, const float* phase, const float* syn_window, const float* tw1, const float* tw2,
                         const float* window_sum, const float* vad_logit, float* wave_out, int B, int T, int n_fft, int hop,
                         int fast_math, void* stream);

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "noise_istft_fwd_sym": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "noise_istft_bwd_sym": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "noise_stft_fwd_fft": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "noise_stft_fwd_fft_ref": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "noise_istft_fwd_fft": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "noise_istft_bwd_fft": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "noise_fft_supported": [_I],

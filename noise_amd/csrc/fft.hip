@@ -51,7 +51,17 @@ __device__ unsigned long long g_fft_stamps[8];
 struct FftDims {
   int B, L, T, hop, F, Lout, accum;
   int ntiles;   // frame tiles per clip; the grid is B * ntiles workgroups, padded to a multiple of 8
+  int mark_floor;   // forward: a clip with a bin far below the 1e-3 magnitude floor gets absmax = floor_mark() (see below)
+  float floor_mag;  // 1e-3f (a run-time value on purpose, see log_floor)
 };
+
+// |log(1e-3)| as the device's logf gives it (evaluated at run time from `floor_mag` = 1e-3f, so that no host-side constant
+// folding can round it differently), and the next float above it.  A clip whose per-clip max carries the mark holds a bin
+// whose magnitude is below 0.9e-3: whatever the summation order, that bin sits on the floor and the clip's max
+// |log-magnitude| is exactly the floor value (magnitudes of [-1, 1] audio stay far below e^6.9), so
+// stft_absmax_refine_kernel has nothing to redo.
+__device__ __forceinline__ float log_floor(float floor_mag) { return fabsf(logf(floor_mag)); }
+__device__ __forceinline__ float floor_mark(float floor_mag) { return __uint_as_float(__float_as_uint(log_floor(floor_mag)) + 1u); }
 
 // Tables (device, caller-provided): win [N] window; tw1 [N2] = e^{-2 pi i j / N2}; tw2 [N2 + 1] = e^{-2 pi i k / N}.
 template <int N2, int FR>
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
           out0[oidx] = lm;
           if (out1 != nullptr) out1[oidx] = FAST ? fast_atan2(xv.y, xv.x) : atan2f(xv.y, xv.x);
           amax = fmaxf(amax, fabsf(lm));
+          if (d.mark_floor && xv.x * xv.x + xv.y * xv.y < 0.81e-6f) amax = fmaxf(amax, floor_mark(d.floor_mag));
         }
       } else {
         // rows of inverse_basis: c_f ws[n] (cos, -sin) / N -> the transform of the windowed gradient times c_f / N
@@ -360,6 +371,109 @@ __global__ __launch_bounds__(16 * FR) void istft_fft_kernel(const float* __restr
   }
 }
 
+// Per-clip normaliser max |log-magnitude| (train/models.py:614-620) in the accumulation order of the dense kernel
+// (stft_frames_kernel in stft.hip: one k-ordered fmaf chain per bin, the order of the reference's conv1d).  The max is
+// attained on the bin of smallest magnitude, a difference of large numbers whose fp32 rounding depends on the summation
+// order by ~1e-4 of the log; the FFT spectrum is as accurate but rounds differently, and every normalised input (and
+// gradient) of the clip inherits that difference.  Only the few bins within RANGE of the FFT max can attain the dense
+// max, so those are recomputed as dense dot products: one lane per candidate, 2 x n_fft sequential fmaf.
+constexpr int REFINE_MAX_CAND = 2048;
+__global__ __launch_bounds__(256) void stft_absmax_refine_kernel(const float* __restrict__ wave, const float* __restrict__ basisT,
+                                                                 const float* __restrict__ logmag, float* __restrict__ absmax,
+                                                                 int L, int T, int F, int n_fft, int hop, int rpad,
+                                                                 float floor_mag) {
+  __shared__ int cand[REFINE_MAX_CAND];
+  __shared__ int ncand;
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float m0 = absmax[b];
+  if (m0 == floor_mark(floor_mag)) {   // a bin far below the floor: the max is the floor in any order
+    if (tid == 0) absmax[b] = log_floor(floor_mag);
+    return;
+  }
+  constexpr float RANGE = 2e-3f;
+  const float* lm = logmag + (size_t)b * F * T;
+  const float* x = wave + (size_t)b * L;
+  const int half = n_fft / 2, total = F * T;
+  float best = 0.f;
+  const float thr = m0 - RANGE;
+  // one lane per candidate: the k-ordered chain of the dense kernel; the operands of 8 steps are requested together
+  auto recompute = [&](int n) {
+    for (int c = tid; c < n; c += 256) {
+      const int i = cand[c], f = i / T, t = i - f * T;
+      const float* bre = basisT + 2 * f;
+      const int s0 = t * hop - half;
+      float re = 0.f, im = 0.f;
+      for (int k0 = 0; k0 < n_fft; k0 += 8) {
+        float xv[8], br[8], bi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u, n_fft - 1);
+          int sidx = s0 + k;
+          if (sidx < 0) sidx = -sidx;
+          if (sidx >= L) sidx = 2 * (L - 1) - sidx;
+          xv[u] = x[sidx];
+          br[u] = bre[(size_t)k * rpad];
+          bi[u] = bre[(size_t)k * rpad + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (k0 + u < n_fft) {
+            re = fmaf(br[u], xv[u], re);
+            im = fmaf(bi[u], xv[u], im);
+          }
+        }
+      }
+      best = fmaxf(best, fabsf(logf(fmaxf(sqrtf(re * re + im * im), 1e-3f))));
+    }
+  };
+  // Fast path: one sweep over the clip's spectrum (every thread requests 8 elements at a time); a list that overflows
+  // (thousands of bins within RANGE of the max: not a signal the path meets) falls back to sweeping in rounds.
+  if (tid == 0) ncand = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < total; i0 += 2048) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = lm[min(i0 + tid + 256 * u, total - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + tid + 256 * u;
+      if (i < total && fabsf(v[u]) >= thr) {
+        const int slot = atomicAdd(&ncand, 1);
+        if (slot < REFINE_MAX_CAND) cand[slot] = i;
+      }
+    }
+  }
+  __syncthreads();
+  const int nall = ncand;   // uniform
+  if (nall <= REFINE_MAX_CAND) {
+    recompute(nall);
+  } else {
+    int base = 0;
+    while (base < total) {   // every value that steers the control flow is uniform over the workgroup
+      __syncthreads();
+      if (tid == 0) ncand = 0;
+      __syncthreads();
+      int i0 = base;
+      while (i0 < total) {
+        const int i = i0 + tid;
+        if (i < total && fabsf(lm[i]) >= thr) cand[atomicAdd(&ncand, 1)] = i;
+        i0 += 256;
+        __syncthreads();
+        const int nc = ncand;
+        __syncthreads();
+        if (nc > REFINE_MAX_CAND - 256) break;
+      }
+      base = i0;
+      recompute(ncand);
+    }
+  }
+  best = wave_reduce_max(best);
+  if ((tid & 63) == 0) red[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) absmax[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 template <int N2, int FR>
 size_t fwd_smem(int hop) {
   return FftLds<N2, FR>::zbytes + (size_t)(N2 + N2 + 1) * 8 + (size_t)(2 * N2) * 4 + (size_t)((FR - 1) * hop + 2 * N2) * 4;
@@ -437,6 +551,27 @@ NOISE_EXPORT int noise_stft_fwd_fft(const float* wave, const float* window, cons
   else
     launch_fwd<0, false>(n_fft, wave, window, tw1, tw2, logmag, phase, (unsigned*)absmax, nullptr, nullptr, nullptr, nullptr, d, st);
   NOISE_CHECK_LAUNCH("noise_stft_fwd_fft");
+  return 0;
+}
+
+// The same transform with the per-clip normaliser evaluated as noise_stft_fwd evaluates it (the reference's conv1d order):
+// the training step's network input.  basisT: the dense kernel's basis layout [n_fft][noise_stft_rpad(n_fft)].
+NOISE_EXPORT int noise_stft_fwd_fft_ref(const float* wave, const float* window, const float* tw1, const float* tw2,
+                                        const float* basisT, float* logmag, float* phase, float* absmax, int B, int L,
+                                        int n_fft, int hop, void* stream) {
+  if (check_fft("noise_stft_fwd_fft_ref", B, n_fft, hop)) return -1;
+  NOISE_REQUIRE(wave && window && tw1 && tw2 && basisT && logmag && absmax, "noise_stft_fwd_fft_ref: null pointer");
+  NOISE_REQUIRE(L > n_fft / 2, "noise_stft_fwd_fft_ref: L=%d too short for reflect padding of %d", L, n_fft / 2);
+  hipStream_t st = (hipStream_t)stream;
+  FftDims d{B, L, L / hop + 1, hop, n_fft / 2 + 1, hop * (L / hop), 0, 0, 1, 1e-3f};
+  hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * B, st);
+  NOISE_REQUIRE(e == hipSuccess, "noise_stft_fwd_fft_ref: memset failed: %s", hipGetErrorString(e));
+  launch_fwd<0, false>(n_fft, wave, window, tw1, tw2, logmag, phase, (unsigned*)absmax, nullptr, nullptr, nullptr, nullptr, d, st);
+  NOISE_CHECK_LAUNCH("noise_stft_fwd_fft_ref");
+  const int F = n_fft / 2 + 1, rpad = (2 * F + 31) / 32 * 32;
+  hipLaunchKernelGGL(stft_absmax_refine_kernel, dim3(B), dim3(256), 0, st, wave, basisT, logmag, absmax, L, d.T, F, n_fft, hop,
+                     rpad, 1e-3f);
+  NOISE_CHECK_LAUNCH("noise_stft_fwd_fft_ref/absmax");
   return 0;
 }
 

@@ -9,6 +9,7 @@ Same constructor, same three registered buffers (`forward_basis`, `inverse_basis
 `inverse` is differentiable w.r.t. `log_magnitude` (the only gradient the training step needs:
 the phase comes from the noisy input).  There is no CPU path: tensors must live on the GPU.
 """
+import os
 import numpy as np
 import torch
 from scipy.signal import get_window
@@ -144,6 +145,8 @@ class STFT(torch.nn.Module):
         self._derived = None  # (key, symmetric, forward layout, inverse layout) rebuilt when buffers move/change
         self.use_symmetry = True  # False forces the general kernels (any basis)
         self.use_fft = True       # False forces the dense-basis kernels
+        # FFT kernels: hardware-rate log / exp / sine / cosine and a polynomial angle instead of the library functions
+        self.fast_math = os.environ.get("NOISE_STFT_FAST", "0") == "1"
 
     # -- kernel-side layouts of the two bases, derived lazily from the registered buffers
     def _bases(self):
@@ -173,30 +176,42 @@ class STFT(torch.nn.Module):
     def num_frames(self, L):
         return L // self.hop_length + 1
 
-    def forward(self, waveform, return_absmax=False, reference_order=False, want_phase=True, fast_math=False):
-        """`reference_order=True` takes the general kernel, which accumulates every bin over the n_fft samples in
-        the order of the reference's conv1d, even when the folded one is available.  The two agree to fp32
-        rounding (the folded one is slightly closer to a float64 evaluation), but on bins near the 1e-3 magnitude
-        floor that rounding is ~5e-5 of the log-magnitude, and the per-clip normaliser max|log-magnitude| of the
-        denoiser (train/models.py:614-620) is usually attained there: the training step asks for the reference's
-        order on the network input so that its normaliser, and with it every gradient, reproduces the
-        reference's to ~1e-6 instead of ~1e-3.
+    def forward(self, waveform, return_absmax=False, reference_order=False, want_phase=True, fast_math=None):
+        """`reference_order=True` takes the general dense kernel, which accumulates every bin over the n_fft samples in
+        the order of the reference's conv1d, even when a faster one is available.  The kernels agree to fp32 rounding
+        (the others are slightly closer to a float64 evaluation), i.e. to ~3e-5 of a log-magnitude on small bins, and
+        the training step asks for the reference's order on the network input so that it reproduces the reference's
+        gradients to ~1e-6 of each tensor: a different rounding of the input moves the bottleneck activations by ~3e-5,
+        which flips a few ReLU6 masks, and with the handful of bottleneck pixels of a small batch one flip is ~1e-2 of a
+        weight-gradient entry (measured on the 4-segment reference fixture: 4e-4 -> 8e-3 with any other input rounding).
+        `reference_order="normaliser"` is the cheaper middle: the spectrum from the FFT kernel, and only the per-clip
+        normaliser max|log-magnitude| (train/models.py:614-620, attained on the bin of smallest magnitude, where the
+        rounding is largest) re-evaluated in the dense order on the few bins that can attain it
+        (`noise_stft_fwd_fft_ref`): bit-identical normaliser at 0.12 ms instead of 0.27 ms per 1280 segments.
         `fast_math=True` (the bf16 inference pipeline; FFT kernels only) computes the log and the angle with
         hardware-rate approximations (about 2e-6 absolute) instead of the library functions."""
         _lib.require_cuda(waveform, self.forward_basis)
+        fast_math = self.fast_math if fast_math is None else fast_math
         B = waveform.shape[0]
         L = waveform.shape[-1]
         wave = waveform.reshape(B, L).contiguous().float()
         T = self.num_frames(L)
         sym, basisT, _, basisF, _ = self._bases()
         sym = sym and not reference_order
-        fft = None if reference_order else self._fft()
+        fft = self._fft()
+        normaliser_only = reference_order == "normaliser" and fft is not None and return_absmax
+        if reference_order and not normaliser_only:
+            fft = None      # the whole transform as dense products in the reference's order
         logmag = torch.empty(B, 1, self.cutoff, T, device=wave.device, dtype=torch.float32)
         # a caller that only needs the magnitudes (the clean target of the spectral loss) skips atan2 and its store
         phase = torch.empty(B, self.cutoff, T, device=wave.device, dtype=torch.float32) if want_phase else None
         absmax = torch.empty(B, device=wave.device, dtype=torch.float32) if return_absmax else None
         nbytes = 4 * B * L + (8 if want_phase else 4) * B * self.cutoff * T
-        if fft is not None:
+        if normaliser_only:
+            _lib.call("noise_stft_fwd_fft_ref", _lib.ptr(wave), _lib.ptr(fft[0]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
+                      _lib.ptr(basisT), _lib.ptr(logmag), _lib.ptr(phase), _lib.ptr(absmax), B, L, self.n_fft,
+                      self.hop_length, _lib.stream(), nbytes=nbytes)
+        elif fft is not None:
             _lib.call("noise_stft_fwd_fft", _lib.ptr(wave), _lib.ptr(fft[0]), _lib.ptr(fft[2]), _lib.ptr(fft[3]),
                       _lib.ptr(logmag), _lib.ptr(phase), _lib.ptr(absmax), B, L, self.n_fft, self.hop_length,
                       int(bool(fast_math)), _lib.stream(), nbytes=nbytes)
@@ -208,8 +223,9 @@ class STFT(torch.nn.Module):
             return logmag, phase, absmax
         return logmag, phase
 
-    def _inverse_raw(self, log_magnitude, phase, vad_logit, fast_math=False):
+    def _inverse_raw(self, log_magnitude, phase, vad_logit, fast_math=None):
         _lib.require_cuda(log_magnitude, phase, self.inverse_basis)
+        fast_math = self.fast_math if fast_math is None else fast_math
         B, _, F, T = log_magnitude.shape
         lm = log_magnitude.contiguous().float()
         ph = phase.contiguous().float()

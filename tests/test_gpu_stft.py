@@ -189,6 +189,30 @@ def test_fft_fast_math(dev, n_fft, hop):
     np.testing.assert_allclose(rec.cpu().numpy()[..., hop:-hop], w.cpu().numpy()[..., hop:-hop], atol=1e-4)
 
 
+@pytest.mark.parametrize("tag,n_fft,hop", CONFIGS)
+def test_reference_order_normaliser(dev, tag, n_fft, hop):
+    """The per-clip normaliser max|log-magnitude| (models.py:614-620) is attained on the bin of smallest magnitude, where
+    fp32 rounding depends on the summation order.  `reference_order="normaliser"` takes the spectrum from the FFT kernel and
+    re-evaluates the bins that can attain the max in the k-ordered chain of the dense kernel: the normaliser must equal
+    the dense kernel's bit for bit (silent clips, clips near the floor and half-silent clips included), while the
+    spectrum is the plain FFT kernel's."""
+    from noise_amd.data import synth_batch
+    st = _stft(n_fft, hop, dev, sym="fft")
+    for B, L, seed in ((300, 8000, 1), (5, 160000, 2), (7, 12345, 3)):
+        x = synth_batch(B, L, dev, seed=seed)[0]
+        x[0] = 0
+        x[1] = x[1] * 1e-3
+        x[2, ..., : L // 2] = 0
+        x[3] = x[3] * 1e-2
+        ld, pd, ad = st.forward(x, return_absmax=True, reference_order=True)
+        lf, pf, af = st.forward(x, return_absmax=True, reference_order="normaliser")
+        lp, pp, ap = st.forward(x, return_absmax=True)
+        assert torch.equal(af, ad)
+        assert torch.equal(lf, lp) and torch.equal(pf, pp)
+        assert (ap != ad).any() or L != 8000      # the plain FFT normaliser does differ on some segments
+        assert float(af[0]) == float(np.float32(abs(ld[0].min().item())))
+
+
 def test_asymmetric_basis_takes_general_kernels(dev):
     from noise_amd import STFT
     st = _stft(320, 160, dev, max_frames=100)
