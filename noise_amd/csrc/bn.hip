@@ -22,6 +22,10 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
   const int c = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = c < C;
   const int cols[2] = {c, C + c};
+  // the per-channel operands are requested together with the slab rows (one memory round trip for the whole kernel)
+  const int cc = ok ? c : 0;
+  const float g_c = gamma[cc], b_c = beta[cc];
+  const float rm_c = running_mean ? running_mean[cc] : 0.f, rv_c = running_mean ? running_var[cc] : 0.f;
   double sums[2];
   slab_column_sums<2>(slab, nrows, 2 * C, cols, ok, red, sums);
   const double s1 = sums[0], s2 = sums[1];
@@ -30,16 +34,16 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * invstd;
+  const float sc = g_c * invstd;
   coef[c] = sc;
-  coef[C + c] = beta[c] - (float)mean * sc;
+  coef[C + c] = b_c - (float)mean * sc;
   coef[2 * C + c] = (float)mean;
   coef[3 * C + c] = invstd;
   coef[4 * C + c] = (float)(mean - (double)(float)mean);   // low part of the batch mean (used by the backward pass)
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_mean[c] = (1.f - momentum) * rm_c + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * rv_c + momentum * (float)unbiased;
   }
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
 }
@@ -112,14 +116,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int c = blockIdx.x * SLAB_COLS + (threadIdx.x & (SLAB_COLS - 1));
   const bool ok = c < C;
   const int cols[2] = {c, C + c};
+  const int cc = ok ? c : 0;     // per-channel operands requested together with the slab rows
+  const float g_c = gamma[cc], m_hi = coef[2 * C + cc], m_lo = coef[4 * C + cc], is_c = coef[3 * C + cc];
   double sums[2];
   slab_column_sums<2>(slab, nrows, row_stride, cols, ok, red, sums);
   const double s1 = sums[0], s2 = sums[1];
   if (threadIdx.x >= SLAB_COLS || !ok) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
-  const double mean = (double)coef[2 * C + c] + (double)coef[4 * C + c], istd = coef[3 * C + c];
-  const double s = (double)gamma[c] * istd;
+  const double mean = (double)m_hi + (double)m_lo, istd = is_c;
+  const double s = (double)g_c * istd;
   const double k1 = s1 / count, k2 = s2 / count;
   // dy = s*(dz - k1) - s*k2*istd*(y - mean);  k1 and mean as hi+lo float pairs
   const float k1h = (float)k1, mh = (float)mean;

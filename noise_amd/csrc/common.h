@@ -138,34 +138,47 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
 
 // Column sums of a slab of per-workgroup partials: slab[r][col], r < nrows (row_stride floats apart), in double.
 // A block covers SLAB_COLS columns x (256 / SLAB_COLS) row lanes (col = first_col + (tid & (SLAB_COLS-1)), row
-// lane = tid / SLAB_COLS): a row lane reads 32 contiguous bytes and walks nrows/32 rows, so even a 2048-row slab
-// is only 16 dependent steps of 4 loads deep.  `red` is 256 doubles of LDS per summed column set; the result is
-// valid in the threads with tid < SLAB_COLS.  Contains barriers: every thread of the block must call it.
+// lane = tid / SLAB_COLS): a row lane reads 32 contiguous bytes of every 32nd row.  The kernels that call this are
+// pure latency (a few workgroups, a slab that the previous kernel has just written): what they cost is the number of
+// DEPENDENT memory round trips, so a lane requests SLAB_BATCH rows of every summed column before it adds the first one
+// (clamped addresses, no branch around the loads): a 1024-row slab is two round trips instead of eight (measured: 6.6 ->
+// 5.8 us per finalize launch; a deeper batch and requesting the per-channel operands ahead add nothing: what is left is
+// the launch boundary behind a kernel that leaves megabytes of dirty lines in the L2s).  The additions
+// run in a fixed order, so the result does not change from run to run.  `red` is 256 doubles of LDS per summed column
+// set; the result is valid in the threads with tid < SLAB_COLS.  Contains barriers: every thread of the block must
+// call it.
 #define SLAB_COLS 8
+#define SLAB_BATCH 16
 template <int NSUM>
 __device__ __forceinline__ void slab_column_sums(const float* __restrict__ slab, int nrows, int row_stride,
                                                  const int (&col)[NSUM], bool col_valid, double* red, double (&out)[NSUM]) {
   constexpr int LANES = 256 / SLAB_COLS;
   const int rl = threadIdx.x / SLAB_COLS;
-  double acc[NSUM][4];
+  double acc[NSUM];
 #pragma unroll
-  for (int j = 0; j < NSUM; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0;
+  for (int j = 0; j < NSUM; ++j) acc[j] = 0.0;
   if (col_valid) {
-    int r = rl;
-    for (; r + 3 * LANES < nrows; r += 4 * LANES) {   // independent chains keep several loads in flight
+    for (int r0 = rl; r0 < nrows; r0 += SLAB_BATCH * LANES) {
+      float v[NSUM][SLAB_BATCH];
 #pragma unroll
-      for (int j = 0; j < NSUM; ++j)
+      for (int u = 0; u < SLAB_BATCH; ++u) {
+        const int r = r0 + u * LANES;
+        const size_t row = (size_t)(r < nrows ? r : nrows - 1) * row_stride;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[j][u] += (double)slab[(size_t)(r + u * LANES) * row_stride + col[j]];
+        for (int j = 0; j < NSUM; ++j) v[j][u] = slab[row + col[j]];
+      }
+#pragma unroll
+      for (int u = 0; u < SLAB_BATCH; ++u) {
+        const bool in = r0 + u * LANES < nrows;
+#pragma unroll
+        for (int j = 0; j < NSUM; ++j) acc[j] += in ? (double)v[j][u] : 0.0;
+      }
     }
-    for (; r < nrows; r += LANES)
-#pragma unroll
-      for (int j = 0; j < NSUM; ++j) acc[j][0] += (double)slab[(size_t)r * row_stride + col[j]];
   }
 #pragma unroll
   for (int j = 0; j < NSUM; ++j) {
     __syncthreads();
-    red[threadIdx.x] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+    red[threadIdx.x] = acc[j];
     __syncthreads();
     double s = 0.0;
     if (threadIdx.x < SLAB_COLS) {

@@ -467,15 +467,24 @@ __global__ __launch_bounds__(256) void fold_jobs_kernel(const noise_fold_job* __
   const int j = blockIdx.x * FOLD_COLS + cl;
   const bool ok = j < jb.ncols;
   const float* col = jb.slab + (ok ? j : 0);
+  // a lane requests 16 rows before it adds the first one: the kernel costs dependent round trips, not bytes
+  constexpr int FB = 16;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int r = rl;
-  for (; r + 3 * LANES < jb.rows; r += 4 * LANES) {
-    a0 += (double)col[(size_t)r * jb.row_stride];
-    a1 += (double)col[(size_t)(r + LANES) * jb.row_stride];
-    a2 += (double)col[(size_t)(r + 2 * LANES) * jb.row_stride];
-    a3 += (double)col[(size_t)(r + 3 * LANES) * jb.row_stride];
+  for (int r0 = rl; r0 < jb.rows; r0 += FB * LANES) {
+    float v[FB];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      const int r = r0 + u * LANES;
+      v[u] = col[(size_t)(r < jb.rows ? r : jb.rows - 1) * jb.row_stride];
+    }
+#pragma unroll
+    for (int u = 0; u < FB; u += 4) {
+      a0 += r0 + u * LANES < jb.rows ? (double)v[u] : 0.0;
+      a1 += r0 + (u + 1) * LANES < jb.rows ? (double)v[u + 1] : 0.0;
+      a2 += r0 + (u + 2) * LANES < jb.rows ? (double)v[u + 2] : 0.0;
+      a3 += r0 + (u + 3) * LANES < jb.rows ? (double)v[u + 3] : 0.0;
+    }
   }
-  for (; r < jb.rows; r += LANES) a0 += (double)col[(size_t)r * jb.row_stride];
   red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (threadIdx.x >= FOLD_COLS || !ok) return;
