@@ -82,15 +82,28 @@ MAIN_KERNEL = {"noise_pw_bwd": "pw_bwd_kernel", "noise_pw_fwd": "pw_gemm_kernel"
                "noise_last_convT_fwd": "last_cell_fwd_kernel", "noise_stft_fwd": "stft_frames_kernel"}
 
 
+PROFILE_ROUND = "r3"      # which committed profile set the quoted (not live-measured) figures come from
+
+
+def _profile(name):
+    for rnd in (PROFILE_ROUND, "r2"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def measured_peaks():
-    """What this GPU model achieved in the micro-benchmarks of scripts/peaks.py (committed under profiles/): streaming
-    copy / fill rates and MFMA issue rates, quoted next to the spec peak the roofline fraction is priced against."""
-    path = os.path.join(ROOT, "profiles", "r2_measured_peaks.json")
-    if not os.path.exists(path):
+    """What this GPU model achieved in the micro-benchmarks of scripts/peaks.py: streaming copy / fill rates and MFMA
+    issue rates, quoted next to the spec peak the roofline fraction is priced against.  NOT measured in this run: read
+    from the committed file named in "source"."""
+    path = _profile("measured_peaks.json")
+    if path is None:
         return None
     with open(path) as f:
         d = json.load(f)
     d.pop("note", None)
+    d["source"] = os.path.relpath(path, ROOT) + " (committed micro-benchmark results, not measured in this run)"
     return d
 
 
@@ -123,6 +136,50 @@ def other_configs(device):
         del m
         torch.cuda.empty_cache()
     out.update(stream_mix_augment_configs(device))
+    return out
+
+
+def other_configs_cpu(seconds_each=6.0):
+    """CPU figures beside `other_configs`, same run, same host cores (stated): the oracle's inference forward on
+    8 x 10 s clips at 320/160 and 512/128 (BASELINE configs[0]), one 0.5 s streaming window (configs[3]), the numpy
+    float64 mixer of the oracle on one core (configs[4]).  Bounded samples: a few seconds each."""
+    import numpy as np
+    from oracle import mixer as omix
+    from oracle import spectral as osp
+    from noise_amd.data import synth_batch
+    threads = int(os.environ.get("OMP_NUM_THREADS") or min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    out = {"cores": threads, "kind": "port (CPU oracle: torch CPU kernels / numpy)"}
+    m = build_model("cpu").eval()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x8 = synth_batch(8, 160000, "cpu", seed=7)[0]
+    x1 = synth_batch(1, 8000, "cpu", seed=9)[0]
+    for tag, n_fft, hop in (("320_160", 320, 160), ("512_128", 512, 128)):
+        bufs = osp.stft_buffers(1300, n_fft, hop)
+        with torch.no_grad():
+            osp.model_forward(x1, sd, bufs, n_fft, hop)
+            n, t0 = 0, time.perf_counter()
+            while n < 1 or (time.perf_counter() - t0 < seconds_each and n < 20):
+                osp.model_forward(x8, sd, bufs, n_fft, hop)
+                n += 1
+            dt = (time.perf_counter() - t0) / n
+        out[f"infer_fp32_8x10s_{tag}_audio_s_per_s"] = round(80.0 / dt, 1)
+        if tag == "320_160":
+            with torch.no_grad():
+                n, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < 2.0:
+                    osp.model_forward(x1, sd, bufs, n_fft, hop)
+                    n += 1
+                dt = (time.perf_counter() - t0) / n
+            out["stream_window_fp32_n1"] = {"hop_ms": round(1e3 * dt, 3), "audio_s_per_s": round(0.2 / dt, 1)}
+    rng = np.random.RandomState(3)
+    clean, noise = rng.randn(160000) * 0.05, rng.randn(160000) * 0.02
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or time.perf_counter() - t0 < 3.0:
+        omix.segmental_snr_mixer(clean, noise, 5, -25)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    out["mix_f64_10s_numpy_1core_audio_s_per_s"] = round(10.0 / dt, 1)
     return out
 
 
@@ -193,15 +250,15 @@ def stream_mix_augment_configs(device):
 
 def pmc_traffic(entry_point, clips=64):
     """HBM bytes per launch of the entry point's main kernel, from the committed PMC passes of this same command
-    (profiles/r2_hbm_traffic_per_kernel.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
-    FETCH_SIZE doubled as gfx950 requires); None when no such profile is available."""
-    path = os.path.join(ROOT, "profiles", "r2_hbm_traffic_per_kernel.json")
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as gfx950 requires); None when
+    no such profile is available.  Returns (bytes, source file): the figure is quoted, not measured in this run."""
+    path = _profile("hbm_traffic_per_kernel.json")
     kernel = MAIN_KERNEL.get(entry_point)
-    if kernel is None or clips != 64 or not os.path.exists(path):   # the passes were taken on the default workload
-        return None
+    if kernel is None or clips != 64 or path is None:   # the passes were taken on the default workload
+        return None, None
     with open(path) as f:
         rec = json.load(f).get(kernel)
-    return int(rec["hbm_bytes_per_dispatch"]) if rec else None
+    return (int(rec["hbm_bytes_per_dispatch"]) if rec else None), os.path.relpath(path, ROOT)
 
 
 def main():
@@ -298,8 +355,11 @@ def main():
     step_ms = 1000 * elapsed / args.steps
 
     achieved = dbytes / 1e6 / dms  # bytes / ms -> GB/s
+    traffic, traffic_src = pmc_traffic(dom, args.clips)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.clips),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (traffic_src + " (PMC passes of this command, committed; not measured in this run)")
+                if traffic_src else None,
                 "algorithmic_bytes_per_launch": int(dbytes / dn),
                 "launches_per_step": dn // args.steps, "avg_launch_ms": round(dms / dn, 4),
                 "share_of_step": round(dms / args.steps / step_ms, 3),
@@ -324,6 +384,8 @@ def main():
             line["other_configs"] = other_configs(device)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+            if "other_configs" in line:
+                line["other_configs"]["cpu"] = other_configs_cpu()
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,8 +1,8 @@
 """Data-parallel training step on the GPU: gradient mean over ranks, per-rank BatchNorm statistics, no buffer
 broadcast (the DDP the reference gets from Lightning's `strategy: auto`, train/configs/spectralv2.yaml:5-8,65,70).
 
-Two ranks are rehearsed on ONE card: (a) as two model replicas in one process ("virtual ranks") checked against
-the CPU oracle's two-batch mean gradient + AdamW, (b) as two real processes whose flat gradient buffers go
+Ranks are rehearsed on ONE card: (a) as two and as four model replicas in one process ("virtual ranks") checked against
+the CPU oracle's mean gradient over the ranks' batches + AdamW, (b) as two real processes whose flat gradient buffers go
 through torch.distributed (gloo, staged through the host), checked against (a)."""
 import os
 import socket
@@ -38,9 +38,9 @@ def _rank_batch(rank):
     return noisy, clean, keep
 
 
-def _virtual_two_rank_step(dev):
-    """Two replicas, one step each into their own flat gradient buffers, summed, AdamW with grad_scale 1/2."""
-    reps = [_build(dev) for _ in range(2)]
+def _virtual_rank_step(dev, world=2):
+    """`world` replicas, one step each into their own flat gradient buffers, summed, AdamW with grad_scale 1/world."""
+    reps = [_build(dev) for _ in range(world)]
     opts = [m.configure_optimizers() for m in reps]
     losses = []
     for r, m in enumerate(reps):
@@ -50,11 +50,15 @@ def _virtual_two_rank_step(dev):
         m.attn_keep_mask = keep.to(torch.uint8).to(dev).contiguous()
         out4 = m._native_step(noisy.to(dev), clean.to(dev), m._take_keep_mask(), want_grad=True)
         losses.append(out4.cpu().numpy().copy())
-    total = reps[0]._flat_grads + reps[1]._flat_grads
+    total = sum(m._flat_grads for m in reps[1:]) + reps[0]._flat_grads
     for m, opt in zip(reps, opts):
         m._flat_grads.copy_(total)
-        opt.step(grad_scale=0.5)
+        opt.step(grad_scale=1.0 / world)
     return reps, total, losses
+
+
+def _virtual_two_rank_step(dev):
+    return _virtual_rank_step(dev, 2)
 
 
 def _oracle_rank(sd, rank, dtype):
@@ -74,35 +78,38 @@ def _oracle_rank(sd, rank, dtype):
     return loss.item(), {k: v.grad.double() for k, v in params.items()}, stats
 
 
-def test_two_virtual_ranks_vs_oracle():
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_vs_oracle(world):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import spectral as osp
     dev = torch.device("cuda:0")
     sd0 = {k: v.detach().cpu().clone() for k, v in _build(dev).state_dict().items()}
-    reps, total, losses = _virtual_two_rank_step(dev)
-    o64 = [_oracle_rank(sd0, r, torch.float64) for r in range(2)]
-    o32 = [_oracle_rank(sd0, r, torch.float32) for r in range(2)]
+    reps, total, losses = _virtual_rank_step(dev, world)
+    o64 = [_oracle_rank(sd0, r, torch.float64) for r in range(world)]
+    o32 = [_oracle_rank(sd0, r, torch.float32) for r in range(world)]
     names = [k for k, _ in reps[0].named_parameters()]
     slices = reps[0]._param_slices
+    inv = 1.0 / world
     worst = ("", 0.0)
     for (k, p), (o, n, shape) in zip(reps[0].named_parameters(), slices):
-        mean_gpu = (0.5 * total[o:o + n]).view(shape).cpu().double().numpy()
-        ref = 0.5 * (o64[0][1][k] + o64[1][1][k]).numpy()
-        ref32 = 0.5 * (o32[0][1][k] + o32[1][1][k]).numpy()
+        mean_gpu = (inv * total[o:o + n]).view(shape).cpu().double().numpy()
+        ref = inv * sum(o64[r][1][k] for r in range(world)).numpy()
+        ref32 = inv * sum(o32[r][1][k] for r in range(world)).numpy()
         scale = max(np.abs(ref).max(), 1e-4)
         e_gpu, e_cpu = np.abs(mean_gpu - ref).max() / scale, np.abs(ref32 - ref).max() / scale
         ratio = e_gpu / max(2e-3, 2 * e_cpu)      # fp32 oracle's own distance to float64 calibrates "equal"
         if ratio > worst[1]:
             worst = (k, ratio)
     assert worst[1] < 1.0, worst
-    for r in range(2):
+    for r in range(world):
         np.testing.assert_allclose(losses[r][0], o64[r][0], rtol=1e-4)
-    # the two replicas took the same update from the same start: bit-identical parameters afterwards
-    assert torch.equal(reps[0]._flat_params, reps[1]._flat_params)
+    # the replicas took the same update from the same start: bit-identical parameters afterwards
+    for m in reps[1:]:
+        assert torch.equal(reps[0]._flat_params, m._flat_params)
     # ... and it is AdamW on the mean gradient
     for (k, p), (o, n, shape) in zip(reps[0].named_parameters(), slices):
-        g = (0.5 * total[o:o + n]).view(shape).cpu()
+        g = (inv * total[o:o + n]).view(shape).cpu()
         w = sd0[k].clone()
         osp.adamw_step(w, g, torch.zeros_like(w), torch.zeros_like(w), 1)
         np.testing.assert_allclose(p.detach().cpu().numpy(), w.numpy(), rtol=2e-6, atol=2e-7, err_msg=k)

@@ -31,8 +31,8 @@ def test_oracle_protocol_delay_and_hop():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graph", [True, False], ids=["hipgraph", "eager"])
-def test_streaming_matches_oracle(golden_dir, graph):
+@pytest.mark.parametrize("graph,N", [(True, 3), (False, 3), (True, 1)], ids=["hipgraph", "eager", "one-stream"])
+def test_streaming_matches_oracle(golden_dir, graph, N):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import spectral as osp
@@ -51,7 +51,7 @@ def test_streaming_matches_oracle(golden_dir, graph):
         out = out[0] if isinstance(out, (tuple, list)) else out
         return out.reshape(-1).numpy()
 
-    N, frames, n_chunks = 3, 160, 65
+    frames, n_chunks = 160, 65
     gen = torch.Generator().manual_seed(11)
     audio = (torch.randn(N, n_chunks * frames, generator=gen) * 0.1).clamp(-1, 1)
     ref = [WindowStream(cpu_forward) for _ in range(N)]
