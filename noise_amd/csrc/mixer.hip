@@ -91,6 +91,7 @@ __global__ __launch_bounds__(MIX_THREADS) void snr_mix_kernel(
     clean_out[u * L + i] = ao;
     noise_out[u * L + i] = bo;
     noisy_out[u * L + i] = y;
+    if (noisy_f32) noisy_f32[u * L + i] = (float)y;   // rewritten by pass 3 in the rare clipping case
     my = fmax(my, fabs(y));
     pc = fmax(pc, fabs(ao));
     pn = fmax(pn, fabs(bo));
@@ -118,9 +119,6 @@ __global__ __launch_bounds__(MIX_THREADS) void snr_mix_kernel(
     }
     if (peaks_out) sy = block_sum(sy, red);
     level = (int)(20.0 * log10(scn / peak * (rmsnoisy + MIX_EPS)));
-  } else if (noisy_f32) {
-    // every thread re-reads the elements it wrote itself in pass 2
-    for (long i = tid; i < L; i += MIX_THREADS) noisy_f32[u * L + i] = (float)noisy_out[u * L + i];
   }
   if (tid == 0) {
     level_out[u] = level;

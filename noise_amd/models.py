@@ -521,8 +521,9 @@ class VADSpectralV2(_LightningModule):
         stft = self.stft
         # the network input keeps the reference's accumulation order (see STFT.forward): its per-clip normaliser is
         # sensitive to fp32 rounding, and gradients are compared against the reference's
-        lm_n, ph, absmax = stft.forward(noisy.view(B, 1, 1, seg), return_absmax=True, reference_order=self.reference_order_stft)
-        lm_c, _ = stft.forward(clean.view(B, 1, 1, seg), want_phase=False)
+        lm_n, ph, absmax = stft.forward(noisy.view(B, 1, 1, seg), return_absmax=True, reference_order=self.reference_order_stft,
+                                        fast_math=False)
+        lm_c, _ = stft.forward(clean.view(B, 1, 1, seg), want_phase=False, fast_math=False)
         _, _, H, W = lm_n.shape
         training = self.training
         if keep is not None:
@@ -532,7 +533,7 @@ class VADSpectralV2(_LightningModule):
                 raise ValueError(f"attn_keep_mask must be a contiguous uint8 tensor of shape {want} on {dev}, got "
                                  f"{tuple(keep.shape)} {keep.dtype} on {keep.device}")
         plan, enh, vad = self._spectral(lm_n, absmax, training, keep, self._next_seed())
-        wave = stft._inverse_raw(enh.view(B, 1, H, W), ph, None)
+        wave = stft._inverse_raw(enh.view(B, 1, H, W), ph, None, fast_math=False)
         Lw = wave.shape[-1]
         if Lw != seg:
             raise RuntimeError(f"iSTFT output length {Lw} != segment length {seg}: hop_length must divide {seg} "

@@ -146,7 +146,10 @@ class STFT(torch.nn.Module):
         self.use_symmetry = True  # False forces the general kernels (any basis)
         self.use_fft = True       # False forces the dense-basis kernels
         # FFT kernels: hardware-rate log / exp / sine / cosine and a polynomial angle instead of the library functions
-        self.fast_math = os.environ.get("NOISE_STFT_FAST", "0") == "1"
+        # (against float64 the spectrum is within 1.3e-6 of its largest bin instead of 2.3e-7, the reconstruction within
+        # 1e-7 either way; the parity bar is 1e-5).  The default of `forward` / `inverse` calls that do not say; the
+        # training step always asks for the library functions.  NOISE_STFT_FAST=0 turns it off.
+        self.fast_math = os.environ.get("NOISE_STFT_FAST", "1") != "0"
 
     # -- kernel-side layouts of the two bases, derived lazily from the registered buffers
     def _bases(self):

@@ -28,7 +28,7 @@ def clean_noise_block(block_index, n, length, seed, device):
     return clean, noise, g
 
 
-def generate_shard(n_files, rank=0, world=1, length=160000, seed=0, block=256, params=None, stfts=(), source=None,
+def generate_shard(n_files, rank=0, world=1, length=160000, seed=0, block=1024, params=None, stfts=(), source=None,
                    sink=None, device="cuda"):
     """Mixes (and featurizes) this rank's share of `n_files` utterances.
 
@@ -37,6 +37,9 @@ def generate_shard(n_files, rank=0, world=1, length=160000, seed=0, block=256, p
     seed, device) -> (clean, noise, generator) replaces the synthetic audio.  sink(block_index, first_file_index, out)
     receives every finished block: out = dict(clean, noise, noisy (n, length) float64, level (n,), snr (n,),
     kept (n,) bool, features [(logmag, phase), ...]).  Returns counters and a per-block checksum of the noisy audio.
+    `block` utterances are mixed per launch (one workgroup per utterance: blocks of 1024 x 10 s fill the GPU, blocks of
+    256 leave the mixer at 3.6 instead of 4.2 TB/s); everything random in a block is seeded by (seed, block index), so
+    results depend on `block` but not on the number of ranks.
     """
     params = params or dict(snr_lower=-5, snr_upper=20, target_level_lower=-35, target_level_upper=-15)
     source = source or clean_noise_block

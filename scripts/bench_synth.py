@@ -14,9 +14,10 @@ from noise_amd import STFT, _lib, synth
 
 dev = torch.device("cuda:0")
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-block, L = 256, 160000
+block = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+L = 160000
 # "real audio": four blocks of utterance pairs prepared once (a caller with wav files fills them from disk)
-pool = [synth.clean_noise_block(b, block, L, 0, dev)[:2] for b in range(4)]
+pool = [synth.clean_noise_block(b, block, L, 0, dev)[:2] for b in range(2)]
 
 
 def source(b, n, length, seed, device):
@@ -27,7 +28,7 @@ def source(b, n, length, seed, device):
 
 
 sts = [STFT(1200, 320, 160, 320, "hann").to(dev), STFT(1300, 512, 128, 512, "hann").to(dev)]
-synth.generate_shard(block, 0, 1, length=L, block=block, stfts=sts, source=source)
+synth.generate_shard(n_files, 0, 1, length=L, block=block, stfts=sts, source=source)   # warm-up: allocator, code objects
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 st = synth.generate_shard(n_files, 0, 1, length=L, block=block, stfts=sts, source=source)

@@ -35,6 +35,8 @@ LAYERS = [("enc1.dw", 32, 81, 33, 1, 0, 0), ("enc2.dw", 48, 81, 33, 2, 0, 0), ("
           ("dec3.dw", 16, 81, 33, 1, 1, 1), ("dec2.dw", 72, 41, 17, 2, 1, 0), ("dec1.dw", 96, 21, 9, 2, 1, 0)]
 SETTINGS = [(0, 0), (8, 2048), (16, 2048), (8, 1024), (16, 1024), (8, 4096), (8, 65536), (12, 65536), (16, 65536),
             (24, 65536), (4, 65536)]
+if os.environ.get("WALK_SWEEP") == "occupancy":      # fewer workgroups than the GPU can hold: how much does occupancy matter?
+    SETTINGS = [(16, 256), (16, 512), (16, 768), (16, 1024), (16, 2048)]
 if len(sys.argv) > 1:
     LAYERS = [l for l in LAYERS if l[0] in sys.argv[1:]]
 

@@ -206,7 +206,7 @@ def test_reference_order_normaliser(dev, tag, n_fft, hop):
         x[3] = x[3] * 1e-2
         ld, pd, ad = st.forward(x, return_absmax=True, reference_order=True)
         lf, pf, af = st.forward(x, return_absmax=True, reference_order="normaliser")
-        lp, pp, ap = st.forward(x, return_absmax=True)
+        lp, pp, ap = st.forward(x, return_absmax=True, fast_math=False)
         assert torch.equal(af, ad)
         assert torch.equal(lf, lp) and torch.equal(pf, pp)
         assert (ap != ad).any() or L != 8000      # the plain FFT normaliser does differ on some segments
