@@ -198,14 +198,18 @@ class FusedDenoiser:
         self.enh = torch.empty(B, H, W, **f32)
         self.pinned = 0
         self._wkey = None
+        self._wtensors = None
 
     def weights_key(self):
         """Identity of the values the folded weight images were made from: autograd versions catch in-place tensor
         writes, the net's update counter catches writes through raw device pointers (fused AdamW, running statistics
         of a training forward, state_dict loads), the data pointer catches reallocation."""
         net = self.net
-        return (net._weights_epoch,) + tuple(t._version for t in net.state_dict(keep_vars=True).values()) + \
-            (next(net.parameters()).data_ptr(),)
+        first = next(net.parameters())
+        ts = self._wtensors
+        if ts is None or ts[0] is not first:       # tensor objects replaced (.to(), a new Parameter): list them again
+            ts = self._wtensors = list(net.parameters()) + list(net.buffers())
+        return (net._weights_epoch, first.data_ptr()) + tuple(t._version for t in ts)
 
     def _weights(self):
         net = self.net
