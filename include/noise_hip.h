@@ -367,6 +367,40 @@ int noise_loss_finalize(const double* spec_partial, int n_spec, long spec_count,
 int noise_adamw_step(float* p, const float* g, float* m, float* v, long long* step, long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* ---- once-for-all spectral U-Net forward (train/layers.py:496-668): every width, kernel size and depth is a run-time
+ * choice, so these kernels are shape-generic (NHWC fp32, channel counts multiples of 4 up to any width).  Convolutions
+ * write their raw output plus per-workgroup partial sums of y and y*y (`slab`: noise_ofa_max_rows() rows of 2C floats,
+ * `*rows` = rows written), which noise_bn_finalize_fwd / noise_bn_coef_eval turn into the [scale|shift] the consumer
+ * applies while loading (DynamicBatchNorm2d on the leading channels, layers.py:284-308). */
+int noise_ofa_max_rows(void);
+/* first layer (layers.py:543-550 through :253-272): 1 -> C channels, 3x3, stride 2, padding 1, on x [B][H][W] padded with
+ * hp zero rows at the top and wp zero columns at the left (layers.py:646); w = Conv2d weight [Cmax][1][3][3] */
+int noise_ofa_first_conv(const float* x, const float* w, float* out, float* slab, int* rows, int B, int H, int W, int hp,
+                         int wp, int C, void* stream);
+/* DynamicSeparableConv2d.get_active_filter (layers.py:162-196): centre k x k of the [Cmax][1][kmax][kmax] depthwise
+ * weight, passed through the kmax->k1 matrix m1 and the k1->k2 matrix m2 (null: no such step) while the current size
+ * exceeds k; written tap-major, wt[k*k][C] */
+int noise_ofa_dw_filter(const float* weight, int kmax, const float* m1, int k1, const float* m2, int k2, int k, int C,
+                        float* wt, void* stream);
+/* depthwise k x k conv2d / conv_transpose2d, stride 1 or 2, padding k/2 (layers.py:198-215) of the lazily normalised
+ * source with the filter from noise_ofa_dw_filter */
+int noise_ofa_dw(const float* src_y, const float* src_coef, int src_relu6, const float* wt, float* out, float* slab,
+                 int* rows, int B, int Hi, int Wi, int C, int k, int stride, int transposed, void* stream);
+/* DynamicPointConv2d with kernel 1 (layers.py:253-272): out [npix][N] = a [npix][K] x W[:N, :K]^T, W row stride ldw */
+int noise_ofa_pw(const float* src_y, const float* src_coef, int src_relu6, const float* W, int ldw, float* out,
+                 float* slab, int* rows, long npix, int K, int N, void* stream);
+/* block output (layers.py:454-458, :662): out [B][Ho][Wo][C] = act(scale*y + shift) cropped from the end of y
+ * [B][Hy][Wy][C], + res (same shape as out, or null) + skip [B][Hs][Ws][C] cropped from the end (or null) */
+int noise_ofa_apply(const float* y, const float* coef, int relu6, int Hy, int Wy, const float* res, const float* skip,
+                    int Hs, int Ws, float* out, int B, int Ho, int Wo, int C, void* stream);
+/* last layer (layers.py:556-564): C -> 1 transposed 3x3, stride 2, padding 1; w = ConvTranspose2d weight [Cmax][1][3][3];
+ * out [B][2Hi-1][2Wi-1] raw, slab rows of 2 floats */
+int noise_ofa_last_convT(const float* src_y, const float* src_coef, int src_relu6, const float* w, float* out,
+                         float* slab, int* rows, int B, int Hi, int Wi, int C, void* stream);
+/* network output (layers.py:352-360, :666): one-channel BatchNorm (coef = [scale, shift]) + ReLU6, cropped from the end */
+int noise_ofa_final(const float* y, const float* coef, int relu6, float* out, int B, int Hy, int Wy, int H, int W,
+                    void* stream);
+
 /* ---- micro-benchmarks of the two rooflines (no counterpart in the reference; not on the product path) ----------- */
 /* dst = src (n floats, n % 4 == 0): 8 * n bytes of HBM traffic */
 int noise_bench_copy(const float* src, float* dst, long n, void* stream);

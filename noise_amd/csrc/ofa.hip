@@ -1,0 +1,507 @@
+// Shape-generic NHWC fp32 kernels for the once-for-all spectral U-Net forward (train/layers.py:496-668), gfx950.
+//
+// That network is the spectral denoiser with every dimension made a run-time choice: the depthwise kernel is the centre
+// k x k of a 7 x 7 filter passed through learned 25x25 / 9x9 matrices (layers.py:162-196), 1x1 convolutions and
+// BatchNorms use the leading channels of their maximum-width parameters (layers.py:253-272, :284-308), blocks at the
+// end of a stage can be skipped and stride-1 blocks with equal widths are residual (layers.py:457-458).  Channel
+// counts run from 8 to 1920, so nothing here is specialised to a width: a 1x1 convolution is an fp32 MFMA product tiled
+// over pixels, output channels and input-channel chunks, with the weight matrix read in place (row stride = maximum
+// input width); the depthwise convolution (plain or transposed, any odd k <= 7, stride 1 or 2) is a gather per output
+// pixel.  The tensors follow the lazy BatchNorm protocol of the other kernels: a convolution writes its raw output and
+// per-workgroup partial sums of y and y*y (slab rows of 2C floats, folded by noise_bn_finalize_fwd into [scale|shift]),
+// and the consumer applies scale, shift and ReLU6 while loading.  Block outputs are materialised by the apply kernel,
+// which also adds the residual input and the (cropped) encoder skip (layers.py:662).
+#include "lazy.h"
+
+namespace {
+
+constexpr int OFA_MAX_ROWS = 1024;   // rows of a partial slab = cap of the pixel dimension of a grid
+
+// ---- thread layout of the channel-vector kernels ---------------------------------------------------------------------
+// A block is cl channel lanes (one float4 of channels each) x 256/cl pixel lanes; blockIdx.x walks channel chunks,
+// blockIdx.y starts the pixel walk.  cl is a power of two <= 64 chosen on the host from C.
+struct CvLane {
+  int c;        // first of the lane's 4 channels (clamped into range)
+  bool ok;      // the lane's channels exist
+  int pl, PL;   // pixel lane and number of pixel lanes
+};
+
+__device__ __forceinline__ CvLane cv_lane(int C, int cl) {
+  CvLane r;
+  const int cgl = threadIdx.x & (cl - 1);
+  r.PL = 256 / cl;
+  r.pl = threadIdx.x / cl;
+  const int cg = blockIdx.x * cl + cgl, CG = C >> 2;
+  r.ok = cg < CG;
+  r.c = 4 * (r.ok ? cg : CG - 1);
+  return r;
+}
+
+// per-channel partial sums of a block -> one slab row ([sum(C) | sum of squares(C)]); every thread of the block calls it
+__device__ __forceinline__ void cv_stats(const CvLane& L, int C, int cl, float4 s1, float4 s2, float* __restrict__ slab) {
+  __shared__ float red[256 * 8];
+  float* mine = red + threadIdx.x * 8;
+  st4(mine, s1);
+  st4(mine + 4, s2);
+  __syncthreads();
+  if (L.pl == 0 && L.ok) {
+    float4 a = f4(0.f), b = f4(0.f);
+    for (int r = 0; r < L.PL; ++r) {
+      a = a + ld4(red + (r * cl + threadIdx.x) * 8);
+      b = b + ld4(red + (r * cl + threadIdx.x) * 8 + 4);
+    }
+    float* row = slab + (size_t)blockIdx.y * 2 * C;
+    st4(row + L.c, a);
+    st4(row + C + L.c, b);
+  }
+}
+
+// ---- first layer: 1 -> C, 3x3, stride 2, zero padding 1, on the input padded at the top / left (layers.py:646) ---------
+struct FirstDims {
+  int B, H, W, hp, wp, Ho, Wo, C, cl;
+};
+
+__global__ __launch_bounds__(256) void ofa_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ out, float* __restrict__ slab, FirstDims d) {
+  const CvLane L = cv_lane(d.C, d.cl);
+  float4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = make_float4(w[(L.c + 0) * 9 + t], w[(L.c + 1) * 9 + t], w[(L.c + 2) * 9 + t], w[(L.c + 3) * 9 + t]);
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  const long npix = (long)d.B * d.Ho * d.Wo;
+  for (long p = (long)blockIdx.y * L.PL + L.pl; p < npix; p += (long)gridDim.y * L.PL) {
+    const int wo = (int)(p % d.Wo);
+    const long t = p / d.Wo;
+    const int ho = (int)(t % d.Ho), b = (int)(t / d.Ho);
+    float4 acc = f4(0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * ho - 1 + ky - d.hp;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * wo - 1 + kx - d.wp;
+        const bool in = iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+        const float v = in ? x[((size_t)b * d.H + (in ? iy : 0)) * d.W + (in ? ix : 0)] : 0.f;
+        acc = fma4(f4(v), wt[ky * 3 + kx], acc);
+      }
+    }
+    if (L.ok) {
+      st4(out + (size_t)p * d.C + L.c, acc);
+      s1 = s1 + acc;
+      s2 = fma4(acc, acc, s2);
+    }
+  }
+  cv_stats(L, d.C, d.cl, s1, s2, slab);
+}
+
+// ---- depthwise k x k, plain or transposed, padding k/2 (layers.py:198-215) ----------------------------------------------
+struct DwDims {
+  int B, Hi, Wi, Ho, Wo, C, k, s, cl;
+};
+
+template <bool TR>
+__global__ __launch_bounds__(256) void ofa_dw_kernel(LazySrc src, const float* __restrict__ wt, float* __restrict__ out,
+                                                     float* __restrict__ slab, DwDims d) {
+  const CvLane L = cv_lane(d.C, d.cl);
+  const Lazy4 a = lazy4_init(src, d.C, L.c);
+  const int k = d.k, s = d.s, pad = d.k / 2, C = d.C;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  const long npix = (long)d.B * d.Ho * d.Wo;
+  for (long p = (long)blockIdx.y * L.PL + L.pl; p < npix; p += (long)gridDim.y * L.PL) {
+    const int wo = (int)(p % d.Wo);
+    const long t = p / d.Wo;
+    const int ho = (int)(t % d.Ho), b = (int)(t / d.Ho);
+    float4 acc = f4(0.f);
+    for (int ky = 0; ky < k; ++ky) {
+      int iy;
+      bool vy;
+      if (TR) {   // output row ho receives input row iy through tap ky when ho = iy*s - pad + ky
+        const int u = ho + pad - ky;
+        iy = u / s;
+        vy = u >= 0 && u - iy * s == 0 && iy < d.Hi;
+      } else {
+        iy = ho * s - pad + ky;
+        vy = iy >= 0 && iy < d.Hi;
+      }
+      if (!vy) continue;
+      const float* rowp = a.y + ((size_t)b * d.Hi + iy) * d.Wi * C + L.c;
+      const float* wrow = wt + (size_t)ky * k * C + L.c;
+      for (int kx = 0; kx < k; ++kx) {
+        int ix;
+        bool vx;
+        if (TR) {
+          const int u = wo + pad - kx;
+          ix = u / s;
+          vx = u >= 0 && u - ix * s == 0 && ix < d.Wi;
+        } else {
+          ix = wo * s - pad + kx;
+          vx = ix >= 0 && ix < d.Wi;
+        }
+        if (vx) acc = fma4(lazy4_act(a, ld4(rowp + (size_t)ix * C)), ld4(wrow + (size_t)kx * C), acc);
+      }
+    }
+    if (L.ok) {
+      st4(out + (size_t)p * C + L.c, acc);
+      s1 = s1 + acc;
+      s2 = fma4(acc, acc, s2);
+    }
+  }
+  cv_stats(L, C, d.cl, s1, s2, slab);
+}
+
+// ---- the active depthwise filter (layers.py:162-196), written tap-major: wt[tap][c] ---------------------------------------
+// One thread per channel: centre crop of the current filter, times the transform matrix (y_j = sum_i x_i M[j][i]), for
+// each step from the maximum size down to the active one.
+__global__ void ofa_dw_filter_kernel(const float* __restrict__ weight, int kmax, const float* __restrict__ m1, int k1,
+                                     const float* __restrict__ m2, int k2, int k, int C, float* __restrict__ wt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float f[49], g[49];
+  int cur = kmax;
+  for (int i = 0; i < kmax * kmax; ++i) f[i] = weight[(size_t)c * kmax * kmax + i];
+  for (int step = 0; step < 2; ++step) {
+    const float* M = step == 0 ? m1 : m2;
+    const int tk = step == 0 ? k1 : k2;
+    if (M == nullptr || cur <= k) break;
+    const int st = cur / 2 - tk / 2, n = tk * tk;
+    for (int i = 0; i < tk; ++i)
+      for (int j = 0; j < tk; ++j) g[i * tk + j] = f[(st + i) * cur + st + j];
+    for (int j = 0; j < n; ++j) {
+      float acc = 0.f;
+      for (int i = 0; i < n; ++i) acc = fmaf(g[i], M[j * n + i], acc);
+      f[j] = acc;
+    }
+    cur = tk;
+  }
+  const int st = cur / 2 - k / 2;   // without transform matrices the active filter is the centre crop
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) wt[(size_t)(i * k + j) * C + c] = f[(st + i) * cur + st + j];
+}
+
+// ---- 1x1 convolution with the leading K x N corner of a weight matrix (layers.py:253-272) ---------------------------------
+// out[p][n] = sum_k a[p][k] W[n*ldw + k].  v_mfma_f32_16x16x4_f32 with A = weights (rows = n) and B = activations
+// (columns = pixels), so a lane ends up with 4 consecutive output channels of one pixel.  A workgroup owns NT*16 output
+// channels (blockIdx.x) and walks 64-pixel tiles from blockIdx.y; both operands pass through LDS in chunks of 32 input
+// channels (row pitch 36 floats: 16-byte aligned rows, two lanes per bank).
+struct PwGDims {
+  long npix;
+  int K, N, ldw;
+};
+constexpr int PWG_KC = 32, PWG_PITCH = 36;
+
+template <int NT>
+__global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* __restrict__ W, float* __restrict__ out,
+                                                     float* __restrict__ slab, PwGDims d) {
+  __shared__ float As[64 * PWG_PITCH];
+  __shared__ float Ws[NT * 16 * PWG_PITCH];
+  __shared__ float red[4 * 2 * NT * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int K = d.K, N = d.N;
+  const int n0 = blockIdx.x * NT * 16;
+  const float alo = src.relu6 ? 0.f : -INFINITY, ahi = src.relu6 ? 6.f : INFINITY;
+  float4 s1[NT], s2[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) s1[m] = s2[m] = f4(0.f);
+  const long ntiles = (d.npix + 63) / 64;
+  for (long tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+    const long p0 = tile * 64;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += PWG_KC) {
+      // stage the activated input chunk (64 pixels x 32 channels) and the weight chunk (NT*16 rows x 32 channels)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, pr = idx >> 3, kq = idx & 7, kk = k0 + 4 * kq;
+        const long pix = p0 + pr;
+        const bool in = pix < d.npix && kk < K;
+        const int kc = in ? kk : 0;
+        float4 v = ld4(src.y + (size_t)(in ? pix : 0) * K + kc);
+        if (src.coef != nullptr) v = fma4(v, ld4(src.coef + kc), ld4(src.coef + K + kc));
+        v = clamp4(v, alo, ahi);
+        st4(As + pr * PWG_PITCH + 4 * kq, in ? v : f4(0.f));
+      }
+#pragma unroll
+      for (int i = 0; i < NT / 2; ++i) {
+        const int idx = tid + 256 * i, nr = idx >> 3, kq = idx & 7, kk = k0 + 4 * kq;
+        const bool in = n0 + nr < N && kk < K;
+        const float4 v = ld4(W + (size_t)(in ? n0 + nr : 0) * d.ldw + (in ? kk : 0));
+        st4(Ws + nr * PWG_PITCH + 4 * kq, in ? v : f4(0.f));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < PWG_KC / 4; ++ks) {
+        const float bv = As[(16 * wave + p) * PWG_PITCH + 4 * ks + q];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * m + p) * PWG_PITCH + 4 * ks + q], bv, acc[m], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    const long pix = p0 + 16 * wave + p;
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      const int n = n0 + 16 * m + 4 * q;
+      const float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+      if (pix < d.npix && n < N) {
+        st4(out + (size_t)pix * N + n, o);
+        s1[m] = s1[m] + o;
+        s2[m] = fma4(o, o, s2[m]);
+      }
+    }
+  }
+  // statistics: over the 16 pixel lanes that share q, then over the 4 waves
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    float v[8] = {s1[m].x, s1[m].y, s1[m].z, s1[m].w, s2[m].x, s2[m].y, s2[m].z, s2[m].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v[e] += __shfl_xor(v[e], o, 64);
+    }
+    if (p == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(wave * 2 + 0) * NT * 16 + 16 * m + 4 * q + e] = v[e];
+        red[(wave * 2 + 1) * NT * 16 + 16 * m + 4 * q + e] = v[4 + e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * NT * 16; i += 256) {
+    const int j = i / (NT * 16), c = i - j * NT * 16;
+    if (n0 + c < N) {
+      float s = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) s += red[(wv * 2 + j) * NT * 16 + c];
+      slab[(size_t)blockIdx.y * 2 * N + (size_t)j * N + n0 + c] = s;
+    }
+  }
+}
+
+// ---- block output: BatchNorm (+ReLU6) of a raw tensor, plus the residual input, plus the cropped skip -------------------
+// out[b][h][w][c] = act(scale*y[b][h+oy][w+ox][c] + shift) + res[b][h][w][c] + skip[b][h+sy][w+sx][c]
+// (layers.py:457-458 residual, :662 skip cropped from the end, :666 output crop).
+struct ApplyDims {
+  int B, Ho, Wo, C, Hy, Wy, Hs, Ws, cl;
+};
+
+__global__ __launch_bounds__(256) void ofa_apply_kernel(LazySrc y, const float* __restrict__ res, const float* __restrict__ skip,
+                                                        float* __restrict__ out, ApplyDims d) {
+  const CvLane L = cv_lane(d.C, d.cl);
+  if (!L.ok) return;
+  const Lazy4 a = lazy4_init(y, d.C, L.c);
+  const int oy = d.Hy - d.Ho, ox = d.Wy - d.Wo, sy = d.Hs - d.Ho, sx = d.Ws - d.Wo, C = d.C;
+  const long npix = (long)d.B * d.Ho * d.Wo;
+  for (long p = (long)blockIdx.y * L.PL + L.pl; p < npix; p += (long)gridDim.y * L.PL) {
+    const int wo = (int)(p % d.Wo);
+    const long t = p / d.Wo;
+    const int ho = (int)(t % d.Ho), b = (int)(t / d.Ho);
+    float4 v = lazy4_at(a, (((size_t)b * d.Hy + ho + oy) * d.Wy + wo + ox) * C + L.c);
+    if (res != nullptr) v = v + ld4(res + (size_t)p * C + L.c);
+    if (skip != nullptr) v = v + ld4(skip + (((size_t)b * d.Hs + ho + sy) * d.Ws + wo + sx) * C + L.c);
+    st4(out + (size_t)p * C + L.c, v);
+  }
+}
+
+// ---- last layer: C -> 1 transposed 3x3, stride 2, padding 1 (layers.py:556-564 through :253-272) --------------------------
+// gl lanes (a power of two >= C/4) share an output pixel and split the channels; the raw single-channel output and its
+// partial sums (slab rows of 2 floats) go to the one-channel BatchNorm.
+struct LastDims {
+  int B, Hi, Wi, Ho, Wo, C, gl;
+};
+
+__global__ __launch_bounds__(256) void ofa_last_kernel(LazySrc src, const float* __restrict__ w, float* __restrict__ out,
+                                                       float* __restrict__ slab, LastDims d) {
+  __shared__ float red[8];
+  const int gl = d.gl, cgl = threadIdx.x & (gl - 1), PL = 256 / gl, pl = threadIdx.x / gl;
+  const int CG = d.C >> 2;
+  const bool ok = cgl < CG;
+  const int c = 4 * (ok ? cgl : CG - 1), C = d.C;
+  const Lazy4 a = lazy4_init(src, C, c);
+  float4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
+  float s1 = 0.f, s2 = 0.f;
+  const long npix = (long)d.B * d.Ho * d.Wo;
+  const long nround = (npix + PL - 1) / PL;   // every lane of a group takes part in the shuffles of every round
+  for (long r = blockIdx.x; r < nround; r += gridDim.x) {
+    const long p = r * PL + pl;
+    const bool pv = p < npix;
+    const long pc = pv ? p : 0;
+    const int wo = (int)(pc % d.Wo);
+    const long t = pc / d.Wo;
+    const int ho = (int)(t % d.Ho), b = (int)(t / d.Ho);
+    float4 acc = f4(0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int u = ho + 1 - ky, iy = u / 2;
+      const bool vy = u >= 0 && (u & 1) == 0 && iy < d.Hi;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int v = wo + 1 - kx, ix = v / 2;
+        const bool in = vy && v >= 0 && (v & 1) == 0 && ix < d.Wi && ok && pv;
+        if (in) acc = fma4(lazy4_at(a, (((size_t)b * d.Hi + iy) * d.Wi + ix) * C + c), wt[ky * 3 + kx], acc);
+      }
+    }
+    float sum = (acc.x + acc.y) + (acc.z + acc.w);
+    for (int o = gl >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (cgl == 0 && pv) {
+      out[p] = sum;
+      s1 += sum;
+      s2 = fmaf(sum, sum, s2);
+    }
+  }
+  s1 = wave_reduce_sum(s1);
+  s2 = wave_reduce_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[(threadIdx.x >> 6) * 2] = s1;
+    red[(threadIdx.x >> 6) * 2 + 1] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) slab[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[threadIdx.x] + red[2 + threadIdx.x]) + (red[4 + threadIdx.x] + red[6 + threadIdx.x]);
+}
+
+// ---- network output: one-channel BatchNorm + ReLU6, cropped from the end to the input size (layers.py:666) ---------------
+__global__ void ofa_final_kernel(const float* __restrict__ y, const float* __restrict__ coef, float* __restrict__ out, int B,
+                                 int Hy, int Wy, int H, int W, int relu6) {
+  const long n = (long)B * H * W;
+  const float sc = coef[0], sh = coef[1];
+  const float lo = relu6 ? 0.f : -INFINITY, hi = relu6 ? 6.f : INFINITY;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int wv = (int)(i % W);
+    const long t = i / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    const float v = fmaf(y[((size_t)b * Hy + h + (Hy - H)) * Wy + wv + (Wy - W)], sc, sh);
+    out[i] = __builtin_amdgcn_fmed3f(v, lo, hi);
+  }
+}
+
+int channel_lanes(int C) {
+  const int CG = C / 4;
+  int cl = 1;
+  while (cl < CG && cl < 64) cl <<= 1;
+  return cl;
+}
+
+int pixel_rows(long npix, int per_block) {
+  long r = (npix + per_block - 1) / per_block;
+  if (r > OFA_MAX_ROWS) r = OFA_MAX_ROWS;
+  if (r < 1) r = 1;
+  return (int)r;
+}
+
+}  // namespace
+
+NOISE_EXPORT int noise_ofa_max_rows(void) { return OFA_MAX_ROWS; }
+
+NOISE_EXPORT int noise_ofa_first_conv(const float* x, const float* w, float* out, float* slab, int* rows, int B, int H, int W,
+                                      int hp, int wp, int C, void* stream) {
+  NOISE_REQUIRE(x && w && out && slab && rows, "noise_ofa_first_conv: null pointer");
+  NOISE_REQUIRE(B > 0 && H > 0 && W > 0 && hp >= 0 && wp >= 0 && C >= 4 && C % 4 == 0, "noise_ofa_first_conv: bad shape");
+  FirstDims d{B, H, W, hp, wp, (H + hp - 1) / 2 + 1, (W + wp - 1) / 2 + 1, C, channel_lanes(C)};
+  const int gy = pixel_rows((long)B * d.Ho * d.Wo, 256 / d.cl * 4);
+  hipLaunchKernelGGL(ofa_first_kernel, dim3(noise_cdiv(C / 4, d.cl), gy), dim3(256), 0, (hipStream_t)stream, x, w, out, slab, d);
+  NOISE_CHECK_LAUNCH("noise_ofa_first_conv");
+  *rows = gy;
+  return 0;
+}
+
+NOISE_EXPORT int noise_ofa_dw_filter(const float* weight, int kmax, const float* m1, int k1, const float* m2, int k2, int k,
+                                     int C, float* wt, void* stream) {
+  NOISE_REQUIRE(weight && wt, "noise_ofa_dw_filter: null pointer");
+  NOISE_REQUIRE(kmax <= 7 && (kmax & 1) && k >= 1 && (k & 1) && k <= kmax && C > 0, "noise_ofa_dw_filter: kernel sizes must be odd "
+                "and at most 7 (got max %d, active %d)", kmax, k);
+  NOISE_REQUIRE((!m1 || ((k1 & 1) && k1 >= 1 && k1 < kmax)) && (!m2 || (m1 && (k2 & 1) && k2 >= 1 && k2 < k1)),
+                "noise_ofa_dw_filter: transform steps must shrink from %d (got %d, %d)", kmax, k1, k2);
+  hipLaunchKernelGGL(ofa_dw_filter_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, weight, kmax, m1, k1, m2,
+                     k2, k, C, wt);
+  NOISE_CHECK_LAUNCH("noise_ofa_dw_filter");
+  return 0;
+}
+
+NOISE_EXPORT int noise_ofa_dw(const float* src_y, const float* src_coef, int src_relu6, const float* wt, float* out, float* slab,
+                              int* rows, int B, int Hi, int Wi, int C, int k, int stride, int transposed, void* stream) {
+  NOISE_REQUIRE(src_y && wt && out && slab && rows, "noise_ofa_dw: null pointer");
+  NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C >= 4 && C % 4 == 0, "noise_ofa_dw: bad shape (C must be a multiple of 4)");
+  NOISE_REQUIRE((k & 1) && k >= 1 && k <= 7 && (stride == 1 || stride == 2), "noise_ofa_dw: k must be odd and <= 7, stride 1 or 2");
+  const int pad = k / 2;
+  const int Ho = transposed ? (Hi - 1) * stride - 2 * pad + k : (Hi + 2 * pad - k) / stride + 1;
+  const int Wo = transposed ? (Wi - 1) * stride - 2 * pad + k : (Wi + 2 * pad - k) / stride + 1;
+  DwDims d{B, Hi, Wi, Ho, Wo, C, k, stride, channel_lanes(C)};
+  const int gy = pixel_rows((long)B * Ho * Wo, 256 / d.cl * 2);
+  const LazySrc src{src_y, src_coef, src_relu6};
+  const dim3 grid(noise_cdiv(C / 4, d.cl), gy);
+  if (transposed)
+    hipLaunchKernelGGL(ofa_dw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, wt, out, slab, d);
+  else
+    hipLaunchKernelGGL(ofa_dw_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, wt, out, slab, d);
+  NOISE_CHECK_LAUNCH("noise_ofa_dw");
+  *rows = gy;
+  return 0;
+}
+
+NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src_relu6, const float* W, int ldw, float* out,
+                              float* slab, int* rows, long npix, int K, int N, void* stream) {
+  NOISE_REQUIRE(src_y && W && out && slab && rows, "noise_ofa_pw: null pointer");
+  NOISE_REQUIRE(npix > 0 && K >= 4 && K % 4 == 0 && N >= 4 && N % 4 == 0 && ldw >= K && ldw % 4 == 0,
+                "noise_ofa_pw: K, N and the weight row stride must be multiples of 4 (K %d, N %d, stride %d)", K, N, ldw);
+  const LazySrc src{src_y, src_coef, src_relu6};
+  const PwGDims d{npix, K, N, ldw};
+  const long ntiles = (npix + 63) / 64;
+  if (N > 64) {
+    // few enough pixel rows that the (N/128) x rows grid stays near two rounds of the GPU
+    int gy = pixel_rows(ntiles, 1);
+    const int gx = noise_cdiv(N, 128), want = noise_cdiv(2048, gx);
+    if (gy > want) gy = want;
+    hipLaunchKernelGGL(ofa_pw_kernel<8>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
+    *rows = gy;
+  } else {
+    const int gy = pixel_rows(ntiles, 1);
+    hipLaunchKernelGGL(ofa_pw_kernel<4>, dim3(1, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
+    *rows = gy;
+  }
+  NOISE_CHECK_LAUNCH("noise_ofa_pw");
+  return 0;
+}
+
+NOISE_EXPORT int noise_ofa_apply(const float* y, const float* coef, int relu6, int Hy, int Wy, const float* res,
+                                 const float* skip, int Hs, int Ws, float* out, int B, int Ho, int Wo, int C, void* stream) {
+  NOISE_REQUIRE(y && out, "noise_ofa_apply: null pointer");
+  NOISE_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && C >= 4 && C % 4 == 0, "noise_ofa_apply: bad shape (C must be a multiple of 4)");
+  NOISE_REQUIRE(Hy >= Ho && Wy >= Wo, "noise_ofa_apply: the source (%d x %d) is smaller than the output (%d x %d)", Hy, Wy, Ho, Wo);
+  NOISE_REQUIRE(!skip || (Hs >= Ho && Ws >= Wo), "noise_ofa_apply: the skip tensor (%d x %d) is smaller than the decoder tensor "
+                "(%d x %d)", Hs, Ws, Ho, Wo);
+  ApplyDims d{B, Ho, Wo, C, Hy, Wy, skip ? Hs : Ho, skip ? Ws : Wo, channel_lanes(C)};
+  const int gy = noise_grid((long)B * Ho * Wo, 256 / d.cl * 4, 4096);
+  const LazySrc src{y, coef, relu6};
+  hipLaunchKernelGGL(ofa_apply_kernel, dim3(noise_cdiv(C / 4, d.cl), gy), dim3(256), 0, (hipStream_t)stream, src, res, skip, out, d);
+  NOISE_CHECK_LAUNCH("noise_ofa_apply");
+  return 0;
+}
+
+NOISE_EXPORT int noise_ofa_last_convT(const float* src_y, const float* src_coef, int src_relu6, const float* w, float* out,
+                                      float* slab, int* rows, int B, int Hi, int Wi, int C, void* stream) {
+  NOISE_REQUIRE(src_y && w && out && slab && rows, "noise_ofa_last_convT: null pointer");
+  NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C >= 4 && C % 4 == 0 && C <= 256, "noise_ofa_last_convT: bad shape (C a multiple of 4, "
+                "at most 256)");
+  LastDims d{B, Hi, Wi, 2 * Hi - 1, 2 * Wi - 1, C, channel_lanes(C)};
+  const int grid = pixel_rows((long)B * d.Ho * d.Wo, 256 / d.gl * 4);
+  const LazySrc src{src_y, src_coef, src_relu6};
+  hipLaunchKernelGGL(ofa_last_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, w, out, slab, d);
+  NOISE_CHECK_LAUNCH("noise_ofa_last_convT");
+  *rows = grid;
+  return 0;
+}
+
+NOISE_EXPORT int noise_ofa_final(const float* y, const float* coef, int relu6, float* out, int B, int Hy, int Wy, int H, int W,
+                                 void* stream) {
+  NOISE_REQUIRE(y && coef && out, "noise_ofa_final: null pointer");
+  NOISE_REQUIRE(B > 0 && H > 0 && W > 0 && Hy >= H && Wy >= W, "noise_ofa_final: the network output (%d x %d) is smaller than the "
+                "input (%d x %d)", Hy, Wy, H, W);
+  hipLaunchKernelGGL(ofa_final_kernel, dim3(noise_grid((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, y, coef, out,
+                     B, Hy, Wy, H, W, relu6);
+  NOISE_CHECK_LAUNCH("noise_ofa_final");
+  return 0;
+}
