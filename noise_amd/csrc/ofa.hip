@@ -111,33 +111,32 @@ __global__ __launch_bounds__(256) void ofa_dw_kernel(LazySrc src, const float* _
     const int wo = (int)(p % d.Wo);
     const long t = p / d.Wo;
     const int ho = (int)(t % d.Ho), b = (int)(t / d.Ho);
+    // taps whose source row / column exists: plain conv iy = ho*s - pad + ky; transposed ho = iy*s - pad + ky, i.e. only
+    // the taps congruent to ho + pad modulo s, walking the source backwards
+    int ky_lo, ky_hi, kx_lo, kx_hi;
+    if (TR) {
+      ky_lo = max(0, ho + pad - s * (d.Hi - 1));
+      ky_lo += (ho + pad - ky_lo) % s;
+      ky_hi = min(k - 1, ho + pad);
+      kx_lo = max(0, wo + pad - s * (d.Wi - 1));
+      kx_lo += (wo + pad - kx_lo) % s;
+      kx_hi = min(k - 1, wo + pad);
+    } else {
+      ky_lo = max(0, pad - ho * s);
+      ky_hi = min(k - 1, d.Hi - 1 + pad - ho * s);
+      kx_lo = max(0, pad - wo * s);
+      kx_hi = min(k - 1, d.Wi - 1 + pad - wo * s);
+    }
+    const int step = TR ? s : 1;
     float4 acc = f4(0.f);
-    for (int ky = 0; ky < k; ++ky) {
-      int iy;
-      bool vy;
-      if (TR) {   // output row ho receives input row iy through tap ky when ho = iy*s - pad + ky
-        const int u = ho + pad - ky;
-        iy = u / s;
-        vy = u >= 0 && u - iy * s == 0 && iy < d.Hi;
-      } else {
-        iy = ho * s - pad + ky;
-        vy = iy >= 0 && iy < d.Hi;
-      }
-      if (!vy) continue;
+    for (int ky = ky_lo; ky <= ky_hi; ky += step) {
+      const int iy = TR ? (ho + pad - ky) / s : ho * s - pad + ky;
       const float* rowp = a.y + ((size_t)b * d.Hi + iy) * d.Wi * C + L.c;
       const float* wrow = wt + (size_t)ky * k * C + L.c;
-      for (int kx = 0; kx < k; ++kx) {
-        int ix;
-        bool vx;
-        if (TR) {
-          const int u = wo + pad - kx;
-          ix = u / s;
-          vx = u >= 0 && u - ix * s == 0 && ix < d.Wi;
-        } else {
-          ix = wo * s - pad + kx;
-          vx = ix >= 0 && ix < d.Wi;
-        }
-        if (vx) acc = fma4(lazy4_act(a, ld4(rowp + (size_t)ix * C)), ld4(wrow + (size_t)kx * C), acc);
+#pragma unroll 4
+      for (int kx = kx_lo; kx <= kx_hi; kx += step) {
+        const int ix = TR ? (wo + pad - kx) / s : wo * s - pad + kx;
+        acc = fma4(lazy4_act(a, ld4(rowp + (size_t)ix * C)), ld4(wrow + (size_t)kx * C), acc);
       }
     }
     if (L.ok) {
@@ -150,32 +149,40 @@ __global__ __launch_bounds__(256) void ofa_dw_kernel(LazySrc src, const float* _
 }
 
 // ---- the active depthwise filter (layers.py:162-196), written tap-major: wt[tap][c] ---------------------------------------
-// One thread per channel: centre crop of the current filter, times the transform matrix (y_j = sum_i x_i M[j][i]), for
-// each step from the maximum size down to the active one.
-__global__ void ofa_dw_filter_kernel(const float* __restrict__ weight, int kmax, const float* __restrict__ m1, int k1,
-                                     const float* __restrict__ m2, int k2, int k, int C, float* __restrict__ wt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float f[49], g[49];
+// A block takes 64 channels: the filters sit in LDS, and each step (centre crop of the current filter, times the transform
+// matrix: y_j = sum_i x_i M[j][i]) runs with one thread per (channel, output tap).
+__global__ __launch_bounds__(256) void ofa_dw_filter_kernel(const float* __restrict__ weight, int kmax, const float* __restrict__ m1,
+                                                            int k1, const float* __restrict__ m2, int k2, int k, int C,
+                                                            float* __restrict__ wt) {
+  __shared__ float f[64 * 49], g[64 * 49];
+  const int c0 = blockIdx.x * 64, nc = min(64, C - c0), kk = kmax * kmax;
+  for (int i = threadIdx.x; i < nc * kk; i += 256) f[(i / kk) * 49 + i % kk] = weight[(size_t)c0 * kk + i];
+  __syncthreads();
   int cur = kmax;
-  for (int i = 0; i < kmax * kmax; ++i) f[i] = weight[(size_t)c * kmax * kmax + i];
+  float* src = f;
+  float* dst = g;
   for (int step = 0; step < 2; ++step) {
     const float* M = step == 0 ? m1 : m2;
     const int tk = step == 0 ? k1 : k2;
     if (M == nullptr || cur <= k) break;
     const int st = cur / 2 - tk / 2, n = tk * tk;
-    for (int i = 0; i < tk; ++i)
-      for (int j = 0; j < tk; ++j) g[i * tk + j] = f[(st + i) * cur + st + j];
-    for (int j = 0; j < n; ++j) {
+    for (int w = threadIdx.x; w < nc * n; w += 256) {
+      const int c = w / n, j = w - c * n;
       float acc = 0.f;
-      for (int i = 0; i < n; ++i) acc = fmaf(g[i], M[j * n + i], acc);
-      f[j] = acc;
+      for (int i = 0; i < n; ++i) acc = fmaf(src[c * 49 + (st + i / tk) * cur + st + i % tk], M[j * n + i], acc);
+      dst[c * 49 + j] = acc;
     }
+    __syncthreads();
+    float* t = src;
+    src = dst;
+    dst = t;
     cur = tk;
   }
-  const int st = cur / 2 - k / 2;   // without transform matrices the active filter is the centre crop
-  for (int i = 0; i < k; ++i)
-    for (int j = 0; j < k; ++j) wt[(size_t)(i * k + j) * C + c] = f[(st + i) * cur + st + j];
+  const int st = cur / 2 - k / 2, n = k * k;   // without transform matrices the active filter is the centre crop
+  for (int w = threadIdx.x; w < nc * n; w += 256) {
+    const int j = w / nc, c = w - j * nc;
+    wt[(size_t)j * C + c0 + c] = src[c * 49 + (st + j / k) * cur + st + j % k];
+  }
 }
 
 // ---- 1x1 convolution with the leading K x N corner of a weight matrix (layers.py:253-272) ---------------------------------
@@ -415,7 +422,7 @@ NOISE_EXPORT int noise_ofa_dw_filter(const float* weight, int kmax, const float*
                 "and at most 7 (got max %d, active %d)", kmax, k);
   NOISE_REQUIRE((!m1 || ((k1 & 1) && k1 >= 1 && k1 < kmax)) && (!m2 || (m1 && (k2 & 1) && k2 >= 1 && k2 < k1)),
                 "noise_ofa_dw_filter: transform steps must shrink from %d (got %d, %d)", kmax, k1, k2);
-  hipLaunchKernelGGL(ofa_dw_filter_kernel, dim3(noise_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, weight, kmax, m1, k1, m2,
+  hipLaunchKernelGGL(ofa_dw_filter_kernel, dim3(noise_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, weight, kmax, m1, k1, m2,
                      k2, k, C, wt);
   NOISE_CHECK_LAUNCH("noise_ofa_dw_filter");
   return 0;

@@ -174,7 +174,7 @@ def test_checkpoint_round_trip(tmp_path):
 
 def test_product_path_has_no_cpu_stand_in(tmp_path):
     """The CPU oracle is test infrastructure: nothing under noise_amd/ may name it, bench.py may only import it inside
-    its CPU-baseline leg, and importing the package without the built library must raise instead of degrading."""
+    its CPU-baseline legs, and importing the package without the built library must raise instead of degrading."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -186,9 +186,12 @@ def test_product_path_has_no_cpu_stand_in(tmp_path):
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{f} imports the oracle"
     bench = open(os.path.join(root, "bench.py"), encoding="utf-8").read()
     imports = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle\b", bench, re.M)]
-    start = bench.index("def cpu_baseline")
-    end = bench.index("\ndef ", start + 1)
-    assert imports and all(start < i < end for i in imports), "bench.py may use the oracle in cpu_baseline() only"
+    legs = []
+    for name in ("def cpu_baseline", "def other_configs_cpu"):       # the two CPU-baseline legs of the bench line
+        start = bench.index(name)
+        legs.append((start, bench.index("\ndef ", start + 1)))
+    assert imports and all(any(a < i < b for a, b in legs) for i in imports), \
+        "bench.py may use the oracle in its CPU-baseline legs only"
     # a missing library is an ImportError that names the file, not a silent fallback
     env = dict(os.environ, NOISE_HIP_LIB=str(tmp_path / "absent.so"), PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", "import noise_amd"], env=env, capture_output=True, text=True, timeout=300)
