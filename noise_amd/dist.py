@@ -28,10 +28,12 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
-def make_grad_all_reduce(group=None):
+def make_grad_all_reduce(group=None, single_rank=False):
     """Returns f(flat_grads) -> scale: sums the flat gradient over ranks in place and returns the 1/world
-    factor that the fused optimizer folds into its update (so the mean is never materialised)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    factor that the fused optimizer folds into its update (so the mean is never materialised).  A group of one rank
+    needs no exchange and gets None, unless `single_rank` asks for the collective anyway (a one-GPU check that the
+    RCCL call path works on this machine)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not single_rank):
         return None
     world = dist.get_world_size(group)
     via_host = dist.get_backend(group) == "gloo"      # rehearsal backend: stage device tensors through the host

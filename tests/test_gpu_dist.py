@@ -180,3 +180,44 @@ def test_two_processes_match_virtual_ranks():
         np.testing.assert_allclose(metrics, 0.5 * (losses[0] + losses[1]), rtol=1e-6)
         assert np.array_equal(bn_mean, reps[rank].model.encoder[0][1].running_mean.cpu().numpy())
     assert not np.array_equal(res[0][5], res[1][5])      # statistics are per rank, never broadcast
+
+
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from noise_amd import dist as ndist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    try:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    except Exception as e:      # no RCCL on this machine: reported, not a failure of the code under test
+        q.put(("unavailable", repr(e)))
+        return
+    noisy, clean, keep = _rank_batch(0)
+    out = []
+    for hook in (None, ndist.make_grad_all_reduce(single_rank=True)):
+        m = _build(dev)
+        opt = m.configure_optimizers()
+        m.attn_keep_mask = keep.to(torch.uint8).to(dev).contiguous()
+        out4 = m.train_step_fused(noisy.to(dev), clean.to(dev), opt, hook)
+        torch.cuda.synchronize()
+        out.append((m._flat_params.cpu().numpy(), m._flat_grads.cpu().numpy(), out4.cpu().numpy()))
+    q.put(("ok", dist.get_backend(), out))
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_on_the_launch_stream():
+    """The production branch of the gradient exchange (backend "nccl" = RCCL, device tensor, the kernels' own stream) in
+    a group of one rank: the sum over one rank must leave the step bit-identical to a step without the hook."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(timeout=120)
+    if res[0] == "unavailable":
+        pytest.skip(f"RCCL process group could not be created here: {res[1]}")
+    assert p.exitcode == 0 and res[1] == "nccl"
+    (p0, g0, l0), (p1, g1, l1) = res[2]
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1) and np.array_equal(l0, l1)
