@@ -379,11 +379,12 @@ int noise_ofa_first_conv(const float* x, const float* w, float* out, float* slab
                          int wp, int C, void* stream);
 /* DynamicSeparableConv2d.get_active_filter (layers.py:162-196): centre k x k of the [Cmax][1][kmax][kmax] depthwise
  * weight, passed through the kmax->k1 matrix m1 and the k1->k2 matrix m2 (null: no such step) while the current size
- * exceeds k; written tap-major, wt[k*k][C] */
+ * exceeds k; written tap-major, wt[k*k][C]; flip != 0 reverses the taps, which is the form noise_ofa_dw wants for a
+ * TRANSPOSED stride-1 layer (conv_transpose2d at stride 1 = conv2d with the flipped filter) */
 int noise_ofa_dw_filter(const float* weight, int kmax, const float* m1, int k1, const float* m2, int k2, int k, int C,
-                        float* wt, void* stream);
+                        int flip, float* wt, void* stream);
 /* depthwise k x k conv2d / conv_transpose2d, stride 1 or 2, padding k/2 (layers.py:198-215) of the lazily normalised
- * source with the filter from noise_ofa_dw_filter */
+ * source with the filter from noise_ofa_dw_filter (flipped there when transposed != 0 and stride == 1) */
 int noise_ofa_dw(const float* src_y, const float* src_coef, int src_relu6, const float* wt, float* out, float* slab,
                  int* rows, int B, int Hi, int Wi, int C, int k, int stride, int transposed, void* stream);
 /* DynamicPointConv2d with kernel 1 (layers.py:253-272): out [npix][N] = a [npix][K] x W[:N, :K]^T, W row stride ldw */

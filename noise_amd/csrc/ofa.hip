@@ -148,12 +148,62 @@ __global__ __launch_bounds__(256) void ofa_dw_kernel(LazySrc src, const float* _
   cv_stats(L, C, d.cl, s1, s2, slab);
 }
 
+// Stride 1 (three of four blocks of a stage): a thread owns 4 channels of 4 consecutive output columns, so a filter row
+// costs K + 3 source loads and K weight loads for 4 K multiply-adds instead of 8 K loads.  A transposed stride-1
+// convolution is the plain one with the filter flipped (the filter kernel writes it that way).
+template <int K>
+__global__ __launch_bounds__(256) void ofa_dw1_kernel(LazySrc src, const float* __restrict__ wt, float* __restrict__ out,
+                                                      float* __restrict__ slab, DwDims d) {
+  const CvLane L = cv_lane(d.C, d.cl);
+  const Lazy4 a = lazy4_init(src, d.C, L.c);
+  constexpr int pad = K / 2;
+  const int C = d.C, H = d.Hi, W = d.Wi;   // output size = input size
+  const int WQ = (W + 3) >> 2;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  const long nquad = (long)d.B * H * WQ;
+  for (long qd = (long)blockIdx.y * L.PL + L.pl; qd < nquad; qd += (long)gridDim.y * L.PL) {
+    const int wq = (int)(qd % WQ);
+    const long t = qd / WQ;
+    const int ho = (int)(t % H), b = (int)(t / H), wo0 = 4 * wq;
+    float4 acc[4] = {f4(0.f), f4(0.f), f4(0.f), f4(0.f)};
+    const int ky_lo = max(0, pad - ho), ky_hi = min(K - 1, H - 1 + pad - ho);
+    for (int ky = ky_lo; ky <= ky_hi; ++ky) {
+      const float* rowp = a.y + ((size_t)b * H + ho - pad + ky) * W * C + L.c;
+      float4 in[K + 3], w[K];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) w[kx] = ld4(wt + (size_t)(ky * K + kx) * C + L.c);
+#pragma unroll
+      for (int u = 0; u < K + 3; ++u) {
+        const int ix = wo0 - pad + u;
+        const bool v = ix >= 0 && ix < W;
+        const float4 r = lazy4_act(a, ld4(rowp + (size_t)(v ? ix : 0) * C));
+        in[u] = make_float4(v ? r.x : 0.f, v ? r.y : 0.f, v ? r.z : 0.f, v ? r.w : 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc[j] = fma4(in[j + kx], w[kx], acc[j]);
+    }
+    if (L.ok) {
+      float* o = out + (((size_t)b * H + ho) * W + wo0) * C + L.c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (wo0 + j < W) {
+          st4(o + (size_t)j * C, acc[j]);
+          s1 = s1 + acc[j];
+          s2 = fma4(acc[j], acc[j], s2);
+        }
+    }
+  }
+  cv_stats(L, C, d.cl, s1, s2, slab);
+}
+
 // ---- the active depthwise filter (layers.py:162-196), written tap-major: wt[tap][c] ---------------------------------------
 // A block takes 64 channels: the filters sit in LDS, and each step (centre crop of the current filter, times the transform
 // matrix: y_j = sum_i x_i M[j][i]) runs with one thread per (channel, output tap).
 __global__ __launch_bounds__(256) void ofa_dw_filter_kernel(const float* __restrict__ weight, int kmax, const float* __restrict__ m1,
                                                             int k1, const float* __restrict__ m2, int k2, int k, int C,
-                                                            float* __restrict__ wt) {
+                                                            int flip, float* __restrict__ wt) {
   __shared__ float f[64 * 49], g[64 * 49];
   const int c0 = blockIdx.x * 64, nc = min(64, C - c0), kk = kmax * kmax;
   for (int i = threadIdx.x; i < nc * kk; i += 256) f[(i / kk) * 49 + i % kk] = weight[(size_t)c0 * kk + i];
@@ -181,7 +231,7 @@ __global__ __launch_bounds__(256) void ofa_dw_filter_kernel(const float* __restr
   const int st = cur / 2 - k / 2, n = k * k;   // without transform matrices the active filter is the centre crop
   for (int w = threadIdx.x; w < nc * n; w += 256) {
     const int j = w / nc, c = w - j * nc;
-    wt[(size_t)j * C + c0 + c] = src[c * 49 + (st + j / k) * cur + st + j % k];
+    wt[(size_t)(flip ? n - 1 - j : j) * C + c0 + c] = src[c * 49 + (st + j / k) * cur + st + j % k];
   }
 }
 
@@ -211,52 +261,82 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* _
 #pragma unroll
   for (int m = 0; m < NT; ++m) s1[m] = s2[m] = f4(0.f);
   const long ntiles = (d.npix + 63) / 64;
-  for (long tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
-    const long p0 = tile * 64;
-    f32x4 acc[NT];
+  const int nchunk = (K + PWG_KC - 1) / PWG_KC;
+  // staging maps: a thread moves 2 float4 of the input chunk (64 pixels x 8 channel quads) and NT/2 of the weight chunk
+  const int kq = tid & 7, r0 = tid >> 3;
+  float4 ra[2], rsc, rsh, rw[NT / 2];
+  unsigned vin = 0;   // bit i: ra[i] holds an existing element; bit 8+i: rw[i] does
+  auto fetch = [&](long tile, int ch) {
+    const int kk = ch * PWG_KC + 4 * kq;
+    const bool kin = kk < K;
+    const int kc = kin ? kk : 0;
+    vin = 0;
 #pragma unroll
-    for (int m = 0; m < NT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += PWG_KC) {
-      // stage the activated input chunk (64 pixels x 32 channels) and the weight chunk (NT*16 rows x 32 channels)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 256 * i, pr = idx >> 3, kq = idx & 7, kk = k0 + 4 * kq;
-        const long pix = p0 + pr;
-        const bool in = pix < d.npix && kk < K;
-        const int kc = in ? kk : 0;
-        float4 v = ld4(src.y + (size_t)(in ? pix : 0) * K + kc);
-        if (src.coef != nullptr) v = fma4(v, ld4(src.coef + kc), ld4(src.coef + K + kc));
-        v = clamp4(v, alo, ahi);
-        st4(As + pr * PWG_PITCH + 4 * kq, in ? v : f4(0.f));
-      }
-#pragma unroll
-      for (int i = 0; i < NT / 2; ++i) {
-        const int idx = tid + 256 * i, nr = idx >> 3, kq = idx & 7, kk = k0 + 4 * kq;
-        const bool in = n0 + nr < N && kk < K;
-        const float4 v = ld4(W + (size_t)(in ? n0 + nr : 0) * d.ldw + (in ? kk : 0));
-        st4(Ws + nr * PWG_PITCH + 4 * kq, in ? v : f4(0.f));
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < PWG_KC / 4; ++ks) {
-        const float bv = As[(16 * wave + p) * PWG_PITCH + 4 * ks + q];
-#pragma unroll
-        for (int m = 0; m < NT; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * m + p) * PWG_PITCH + 4 * ks + q], bv, acc[m], 0, 0, 0);
-      }
-      __syncthreads();
+    for (int i = 0; i < 2; ++i) {
+      const long pix = tile * 64 + r0 + 32 * i;
+      const bool in = kin && pix < d.npix;
+      ra[i] = ld4(src.y + (size_t)(in ? pix : 0) * K + kc);
+      vin |= in ? (1u << i) : 0u;
     }
-    const long pix = p0 + 16 * wave + p;
+    rsc = src.coef ? ld4(src.coef + kc) : f4(1.f);
+    rsh = src.coef ? ld4(src.coef + K + kc) : f4(0.f);
 #pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      const int n = n0 + 16 * m + 4 * q;
-      const float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-      if (pix < d.npix && n < N) {
-        st4(out + (size_t)pix * N + n, o);
-        s1[m] = s1[m] + o;
-        s2[m] = fma4(o, o, s2[m]);
+    for (int i = 0; i < NT / 2; ++i) {
+      const int nr = r0 + 32 * i;
+      const bool in = kin && n0 + nr < N;
+      rw[i] = ld4(W + (size_t)(in ? n0 + nr : 0) * d.ldw + kc);
+      vin |= in ? (256u << i) : 0u;
+    }
+  };
+  long tile = blockIdx.y;
+  int ch = 0;
+  if (tile < ntiles) fetch(tile, 0);
+  f32x4 acc[NT];
+  while (tile < ntiles) {
+    // registers -> LDS (the input chunk normalised and clamped on the way), then request the next chunk so that its
+    // memory round trip runs under this chunk's matrix products
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = clamp4(fma4(ra[i], rsc, rsh), alo, ahi);
+      st4(As + (r0 + 32 * i) * PWG_PITCH + 4 * kq, ((vin >> i) & 1u) ? v : f4(0.f));
+    }
+#pragma unroll
+    for (int i = 0; i < NT / 2; ++i) st4(Ws + (r0 + 32 * i) * PWG_PITCH + 4 * kq, ((vin >> (8 + i)) & 1u) ? rw[i] : f4(0.f));
+    __syncthreads();
+    long ntile = tile;
+    int nch = ch + 1;
+    if (nch == nchunk) {
+      nch = 0;
+      ntile = tile + gridDim.y;
+    }
+    if (ntile < ntiles) fetch(ntile, nch);
+    if (ch == 0) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < PWG_KC / 4; ++ks) {
+      const float bv = As[(16 * wave + p) * PWG_PITCH + 4 * ks + q];
+#pragma unroll
+      for (int m = 0; m < NT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * m + p) * PWG_PITCH + 4 * ks + q], bv, acc[m], 0, 0, 0);
+    }
+    __syncthreads();
+    if (ch == nchunk - 1) {
+      const long pix = tile * 64 + 16 * wave + p;
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        const int n = n0 + 16 * m + 4 * q;
+        const float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        if (pix < d.npix && n < N) {
+          st4(out + (size_t)pix * N + n, o);
+          s1[m] = s1[m] + o;
+          s2[m] = fma4(o, o, s2[m]);
+        }
       }
     }
+    tile = ntile;
+    ch = nch;
   }
   // statistics: over the 16 pixel lanes that share q, then over the 4 waves
 #pragma unroll
@@ -416,14 +496,14 @@ NOISE_EXPORT int noise_ofa_first_conv(const float* x, const float* w, float* out
 }
 
 NOISE_EXPORT int noise_ofa_dw_filter(const float* weight, int kmax, const float* m1, int k1, const float* m2, int k2, int k,
-                                     int C, float* wt, void* stream) {
+                                     int C, int flip, float* wt, void* stream) {
   NOISE_REQUIRE(weight && wt, "noise_ofa_dw_filter: null pointer");
   NOISE_REQUIRE(kmax <= 7 && (kmax & 1) && k >= 1 && (k & 1) && k <= kmax && C > 0, "noise_ofa_dw_filter: kernel sizes must be odd "
                 "and at most 7 (got max %d, active %d)", kmax, k);
   NOISE_REQUIRE((!m1 || ((k1 & 1) && k1 >= 1 && k1 < kmax)) && (!m2 || (m1 && (k2 & 1) && k2 >= 1 && k2 < k1)),
                 "noise_ofa_dw_filter: transform steps must shrink from %d (got %d, %d)", kmax, k1, k2);
   hipLaunchKernelGGL(ofa_dw_filter_kernel, dim3(noise_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, weight, kmax, m1, k1, m2,
-                     k2, k, C, wt);
+                     k2, k, C, flip, wt);
   NOISE_CHECK_LAUNCH("noise_ofa_dw_filter");
   return 0;
 }
@@ -440,10 +520,21 @@ NOISE_EXPORT int noise_ofa_dw(const float* src_y, const float* src_coef, int src
   const int gy = pixel_rows((long)B * Ho * Wo, 256 / d.cl * 2);
   const LazySrc src{src_y, src_coef, src_relu6};
   const dim3 grid(noise_cdiv(C / 4, d.cl), gy);
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && k >= 3) {
+    // the filter must have been written flipped (noise_ofa_dw_filter, flip = 1) when `transposed`
+    const dim3 g1(grid.x, pixel_rows((long)B * Ho * ((Wo + 3) / 4), 256 / d.cl));
+    if (k == 3) hipLaunchKernelGGL(ofa_dw1_kernel<3>, g1, dim3(256), 0, st, src, wt, out, slab, d);
+    else if (k == 5) hipLaunchKernelGGL(ofa_dw1_kernel<5>, g1, dim3(256), 0, st, src, wt, out, slab, d);
+    else hipLaunchKernelGGL(ofa_dw1_kernel<7>, g1, dim3(256), 0, st, src, wt, out, slab, d);
+    NOISE_CHECK_LAUNCH("noise_ofa_dw");
+    *rows = (int)g1.y;
+    return 0;
+  }
   if (transposed)
-    hipLaunchKernelGGL(ofa_dw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, wt, out, slab, d);
+    hipLaunchKernelGGL(ofa_dw_kernel<true>, grid, dim3(256), 0, st, src, wt, out, slab, d);
   else
-    hipLaunchKernelGGL(ofa_dw_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, wt, out, slab, d);
+    hipLaunchKernelGGL(ofa_dw_kernel<false>, grid, dim3(256), 0, st, src, wt, out, slab, d);
   NOISE_CHECK_LAUNCH("noise_ofa_dw");
   *rows = gy;
   return 0;
@@ -457,18 +548,17 @@ NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src
   const LazySrc src{src_y, src_coef, src_relu6};
   const PwGDims d{npix, K, N, ldw};
   const long ntiles = (npix + 63) / 64;
-  if (N > 64) {
-    // few enough pixel rows that the (N/128) x rows grid stays near two rounds of the GPU
-    int gy = pixel_rows(ntiles, 1);
-    const int gx = noise_cdiv(N, 128), want = noise_cdiv(2048, gx);
-    if (gy > want) gy = want;
+  // 128 output channels per workgroup when that still gives the GPU two workgroups per CU, 64 otherwise
+  const bool wide = N > 64 && ntiles * noise_cdiv(N, 128) >= 512;
+  const int gx = noise_cdiv(N, wide ? 128 : 64);
+  int gy = pixel_rows(ntiles, 1);
+  const int want = noise_cdiv(2048, gx);   // few enough pixel rows that gx x rows stays near two rounds of the GPU
+  if (gy > want) gy = want;
+  if (wide)
     hipLaunchKernelGGL(ofa_pw_kernel<8>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
-    *rows = gy;
-  } else {
-    const int gy = pixel_rows(ntiles, 1);
-    hipLaunchKernelGGL(ofa_pw_kernel<4>, dim3(1, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
-    *rows = gy;
-  }
+  else
+    hipLaunchKernelGGL(ofa_pw_kernel<4>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
+  *rows = gy;
   NOISE_CHECK_LAUNCH("noise_ofa_pw");
   return 0;
 }

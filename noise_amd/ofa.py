@@ -21,7 +21,7 @@ from ._lib import ptr
 _P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 _lib.register({
     "noise_ofa_first_conv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "noise_ofa_dw_filter": [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P],
+    "noise_ofa_dw_filter": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
     "noise_ofa_dw": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "noise_ofa_pw": [_P, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _P],
     "noise_ofa_apply": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
@@ -293,8 +293,9 @@ class _Run:
         steps = conv.transform_steps(k) + [(None, 0), (None, 0)]
         (m1, k1), (m2, k2) = steps[0], steps[1]
         wt = self.new(k * k, C)
-        _lib.call("noise_ofa_dw_filter", ptr(conv.conv.weight), kmax, ptr(m1), k1, ptr(m2), k2, k, C, ptr(wt), _lib.stream())
         s, tr = conv.stride, conv.transposed
+        _lib.call("noise_ofa_dw_filter", ptr(conv.conv.weight), kmax, ptr(m1), k1, ptr(m2), k2, k, C, int(tr and s == 1),
+                  ptr(wt), _lib.stream())
         pad = k // 2
         Ho = (Hi - 1) * s - 2 * pad + k if tr else (Hi + 2 * pad - k) // s + 1
         Wo = (Wi - 1) * s - 2 * pad + k if tr else (Wi + 2 * pad - k) // s + 1

@@ -94,7 +94,7 @@ def test_layers_against_torch():
         coef = torch.cat([torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)])
         w = torch.randn(C, 1, k, k, device=dev, generator=g)
         wt = torch.empty(k * k, C, device=dev)
-        _lib.call("noise_ofa_dw_filter", ptr(w), k, None, 0, None, 0, k, C, ptr(wt), _lib.stream())
+        _lib.call("noise_ofa_dw_filter", ptr(w), k, None, 0, None, 0, k, C, int(tr and s == 1), ptr(wt), _lib.stream())
         act = torch.clamp(a * coef[:C] + coef[C:], 0, 6).permute(0, 3, 1, 2)
         fn = F.conv_transpose2d if tr else F.conv2d
         want = fn(act.double(), w.double(), stride=s, padding=k // 2, groups=C).permute(0, 2, 3, 1)
@@ -112,7 +112,7 @@ def test_layers_against_torch():
     f3 = F.linear(f5.view(C, 5, 5)[:, 1:4, 1:4].reshape(C, 9), m53)
     for k, want in ((7, w.view(C, 49)), (5, f5), (3, f3)):
         wt = torch.empty(k * k, C, device=dev)
-        _lib.call("noise_ofa_dw_filter", ptr(w), 7, ptr(m75), 5, ptr(m53), 3, k, C, ptr(wt), _lib.stream())
+        _lib.call("noise_ofa_dw_filter", ptr(w), 7, ptr(m75), 5, ptr(m53), 3, k, C, 0, ptr(wt), _lib.stream())
         torch.testing.assert_close(wt.t(), want, rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError, match="multiples of 4"):
         _lib.call("noise_ofa_pw", ptr(slab), None, 0, ptr(slab), 8, ptr(slab), ptr(slab), ctypes.byref(rows), 10, 6, 8, _lib.stream())
