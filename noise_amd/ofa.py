@@ -222,7 +222,7 @@ class OFASpectralNets(nn.Module):
         for axis, name in ((-2, "H_padding"), (-1, "W_padding")):
             want = H if axis == -2 else W
             while out.shape[axis] < want:
-                if getattr(self, name) > 64:
+                if getattr(self, name) > 256:
                     raise RuntimeError("OFASpectralNets: no padding makes the output cover the input with this sub-network "
                                        "(the active decoder blocks do not undo the encoder's strides)")
                 setattr(self, name, getattr(self, name) + 1)

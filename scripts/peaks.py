@@ -1,5 +1,6 @@
 """Measured peaks of this GPU for the two rooflines: HBM streaming copy and MFMA issue rate (fp32-input and
-half-precision).  Writes profiles/r2_measured_peaks.json, which bench.py cites next to the 8 TB/s spec figure."""
+half-precision).  Writes gpurun_out/measured_peaks.json (copied to profiles/<round>_measured_peaks.json, which bench.py cites
+next to the 8 TB/s spec figure)."""
 import ctypes
 import json
 import os
@@ -53,6 +54,6 @@ for kind, name, flop in ((0, "mfma_f32_16x16x4_TFLOPs", 2048), (1, "mfma_f16_16x
 out["note"] = ("copy: float4 persistent grid-stride kernel (2048 workgroups) over 2 x 4 GiB; copy_oneshot: one workgroup per 4 KiB, non-temporal loads and stores; torch_add: torch.add(a, b, out=b) on the same buffers; fill: torch fill_ of 4 GiB; mfma: 8 waves per SIMD, 4 independent "
                "accumulators per wave, random-free constant operands (clock holds higher than on random data)")
 print(json.dumps(out))
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r2_measured_peaks.json")
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "measured_peaks.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
