@@ -127,3 +127,38 @@ def test_reduced_depth_fails_like_the_reference():
     net.set_active(d=[1, 1, 2, 2, 2, 2, 2, 2])
     with pytest.raises(RuntimeError, match="32 channels, the encoder skip 24"):
         net(torch.randn(1, 1, 33, 33, device="cuda"))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_sub_networks_vs_oracle(seed):
+    """Random input sizes, kernel sizes and widths on a small width table: the HIP forward against the CPU oracle
+    (oracle/ofa.py, itself pinned by the reference's outputs), train mode (incl. the padding search's side effects on the
+    running statistics) and eval mode."""
+    import copy
+    from make_golden_ofa import choose, perturb
+    from noise_amd.ofa import OFASpectralNets
+    from oracle import ofa as oofa
+    rng = np.random.RandomState(100 + seed)
+    ks_list = [[3, 5, 7], [3, 7], [5], [3, 5]][seed % 4]
+    mults = [[0.5, 0.75, 1.0], [1.0], [0.5, 1.0]][seed % 3]
+    torch.manual_seed(seed)
+    net = OFASpectralNets(base_stage_width=[16, 8, 16, 24, 24, 32, 40, 48, 64], kernel_size_list=ks_list,
+                          expand_ratio_list=[2, 3], width_mult_list=mults)
+    perturb(net, seed)
+    choose(net, ks=int(rng.choice(ks_list)), wid=int(rng.randint(len(mults))))
+    ref = copy.deepcopy(net)
+    net = net.cuda()
+    B, H, W = int(rng.randint(1, 4)), int(rng.randint(20, 90)), int(rng.randint(20, 70))
+    x = torch.from_numpy(rng.randn(B, 1, H, W).astype(np.float32))
+    for mode in (True, True, False):
+        net.train(mode)
+        ref.train(mode)
+        want = oofa.forward(ref, x).numpy()
+        got = net(x.cuda()).cpu().numpy()
+        assert got.shape == want.shape == (B, 1, H, W)
+        assert np.abs(got - want).max() <= TOL * max(np.abs(want).max(), 1e-3), (mode, np.abs(got - want).max())
+    assert (net.H_padding, net.W_padding) == (ref.H_padding, ref.W_padding)
+    a, b = net.encoder[3].depth_conv.bn.bn, ref.encoder[3].depth_conv.bn.bn
+    assert int(a.num_batches_tracked) == int(b.num_batches_tracked) > 1
+    c = a.running_mean.numel() if a.running_mean.numel() < 9999 else 0
+    np.testing.assert_allclose(a.running_var.cpu().numpy()[:c], b.running_var.numpy()[:c], rtol=5e-3, atol=1e-5)
