@@ -587,11 +587,13 @@ constexpr int TL_UH = TL_CH + 1, TL_UW = TL_CW + 1, TL_PU = TL_UH * TL_UW, TL_NT
 constexpr int TL_SH = TL_CH + 3, TL_SW = TL_CW + 3, TL_PS = TL_SH * TL_SW;                                // s region
 constexpr int TL_CP = 32 + 8, TL_SP = 16 + 8;
 
-__global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 st[TL_PS * TL_SP];          // s = D2 + A1 (zero outside the image)
   __shared__ __attribute__((aligned(16))) __bf16 a0t[TL_NTU * 16 * TL_CP];     // A0 on the u region
-  __shared__ __attribute__((aligned(16))) _Float16 h2[TL_NTU * 16 * TL_CP];    // depthwise output (channels 16..31 zero)
-  __shared__ __attribute__((aligned(16))) _Float16 ut[TL_NTU * 16 * TL_CP];    // u = D3 + A0 (zero outside the image)
+  // depthwise output (channels 0..15; the 1x1 weights of channels 16..31 are zero) and, in the same rows once a wave has
+  // read them, u = D3 + A0 (zero outside the image): a wave reads its 16 pixels of h2 before it writes their u
+  __shared__ __attribute__((aligned(16))) _Float16 h2[TL_NTU * 16 * TL_CP];
+  _Float16* const ut = h2;
   __shared__ __attribute__((aligned(16))) float pt[TL_NTU * 16 * 12];          // P[pixel][tap]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
 #ifdef FUSED_STAMPS
@@ -614,7 +616,6 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   for (int i = tid; i < TL_NTU * 16 * TL_CP / 8; i += 256) {
     reinterpret_cast<uint4*>(a0t)[i] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4*>(h2)[i] = make_uint4(0, 0, 0, 0);
-    reinterpret_cast<uint4*>(ut)[i] = make_uint4(0, 0, 0, 0);
   }
 
   constexpr int PCS = TL_PS * 2, NIS = (PCS + 255) / 256;        // s pieces (8 channels)
