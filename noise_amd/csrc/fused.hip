@@ -84,6 +84,9 @@ struct TileGeom {
   static constexpr int PIN = IH * IW, NT1 = (PIN + 15) / 16;
   static constexpr int OH = TR ? 2 * TH : TH, OW = TR ? 2 * TW : TW, LOW = TR ? 5 : 4;   // OW = 1 << LOW
   static constexpr int POUT = OH * OW, NT3 = POUT / 16;
+  // Transposed blocks run depthwise + project once per row of cells: the depthwise tile then holds 2 x 32 outputs instead
+  // of 2TH x 32, and the LDS that saves is another resident workgroup per CU.
+  static constexpr int PASSES = TR ? TH : 1, PPOUT = POUT / PASSES, PNT3 = PPOUT / 16;
 };
 
 template <int CIN, int HID, int COUT, bool TR, int TH>
@@ -92,7 +95,7 @@ struct IrCfg {
   static constexpr int KP = rup(CIN, 32), KS1 = KP / 32, IP = KP + 8;
   static constexpr int HT = (HID + 15) / 16, HP = rup(HID, 32), KS3 = HP / 32, HPI = HP + 8, G = (HID + 7) / 8;
   static constexpr int CT = (COUT + 15) / 16;
-  static constexpr int LDS_IN = G_::NT1 * 16 * IP, LDS_H1 = G_::NT1 * 16 * HPI, LDS_H2 = G_::POUT * HPI;   // halves
+  static constexpr int LDS_IN = G_::NT1 * 16 * IP, LDS_H1 = G_::NT1 * 16 * HPI, LDS_H2 = G_::PPOUT * HPI;   // halves
   static constexpr int LDS_W1 = HT * KS1 * 64 * 8, LDS_W3 = CT * KS3 * 64 * 8;                             // halves
   static constexpr int LDS_F = HT * 16 + G_::NT1 * 16;                                                     // floats: b1, pixel mask
   static constexpr size_t LDS_BYTES = (size_t)(LDS_IN + LDS_H1 + LDS_H2 + LDS_W1 + LDS_W3) * 2 + (size_t)LDS_F * 4;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* in_t = reinterpret_cast<_Float16*>(lds_raw);   // [NT1*16][IP]
   _Float16* h1 = in_t + C::LDS_IN;                          // [NT1*16][HPI]  expand output (zero outside the image)
-  _Float16* h2 = h1 + C::LDS_H1;                            // [POUT][HPI]    depthwise output
+  _Float16* h2 = h1 + C::LDS_H1;                            // [PPOUT][HPI]   depthwise output (one pass)
   _Float16* wf1 = h2 + C::LDS_H2;                           // [HT][KS1][64][8] A fragments of the expand weights
   _Float16* wf3 = wf1 + C::LDS_W1;                          // [CT][KS3][64][8]
   float* b1s = reinterpret_cast<float*>(wf3 + C::LDS_W3);   // [HT*16]
@@ -274,65 +277,67 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
     __syncthreads();
     IR_T(2);
 
-    // ---- depthwise 3x3 (stride 2) or its transpose on the hidden tile, + bias, ReLU6 (packed half arithmetic)
-    if (pl < NPL) {
-      if (!TR) {
-        for (int po = pl; po < T::POUT; po += NPL) {
-          const int oy = po >> T::LOW, ox = po & (T::OW - 1);
-          const _Float16* src = h1 + ((2 * oy) * T::IW + 2 * ox) * C::HPI + 8 * cg;
-          f16x8 acc = b2r;
+    f16x8 w3r[C::CT][C::KS3];
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
+    for (int mt = 0; mt < C::CT; ++mt)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-              acc = fma_h8(*reinterpret_cast<const f16x8*>(src + (ky * T::IW + kx) * C::HPI), wdr[3 * ky + kx], acc);
-          *reinterpret_cast<f16x8*>(h2 + po * C::HPI + 8 * cg) = clamp01_h8(acc);
-        }
-      } else {
-        // out[o] += in[i] * w[k] with o = 2i - 1 + k: even outputs take tap 1 of cell i, odd ones tap 2 of i and tap 0 of i+1
-        for (int cell = pl; cell < TH * T::TW; cell += NPL) {
-          const int cy = cell >> 4, cx = cell & 15;
-          const _Float16* src = h1 + (cy * T::IW + cx) * C::HPI + 8 * cg;
-          const f16x8 v00 = *reinterpret_cast<const f16x8*>(src), v01 = *reinterpret_cast<const f16x8*>(src + C::HPI);
-          const f16x8 v10 = *reinterpret_cast<const f16x8*>(src + T::IW * C::HPI);
-          const f16x8 v11 = *reinterpret_cast<const f16x8*>(src + (T::IW + 1) * C::HPI);
-          const f16x8 o00 = fma_h8(v00, wdr[4], b2r);
-          const f16x8 o01 = fma_h8(v01, wdr[3], fma_h8(v00, wdr[5], b2r));
-          const f16x8 o10 = fma_h8(v10, wdr[1], fma_h8(v00, wdr[7], b2r));
-          const f16x8 o11 = fma_h8(v11, wdr[0], fma_h8(v10, wdr[2], fma_h8(v01, wdr[6], fma_h8(v00, wdr[8], b2r))));
-          _Float16* dst = h2 + ((2 * cy) * T::OW + 2 * cx) * C::HPI + 8 * cg;
-          *reinterpret_cast<f16x8*>(dst) = clamp01_h8(o00);
-          *reinterpret_cast<f16x8*>(dst + C::HPI) = clamp01_h8(o01);
-          *reinterpret_cast<f16x8*>(dst + T::OW * C::HPI) = clamp01_h8(o10);
-          *reinterpret_cast<f16x8*>(dst + (T::OW + 1) * C::HPI) = clamp01_h8(o11);
+      for (int ks = 0; ks < C::KS3; ++ks) w3r[mt][ks] = *reinterpret_cast<const f16x8*>(wf3 + ((mt * C::KS3 + ks) * 64 + lane) * 8);
+    const int oy0 = TR ? 2 * y0 : (y0 + 1) / 2, ox0 = TR ? 2 * x0 : (x0 + 1) / 2;
+    char* ob = static_cast<char*>(a.out) + (size_t)b * a.Ho * a.Wo * COUT * (OUT_F32 ? 4 : 2);
+#pragma unroll 1
+    for (int pass = 0; pass < T::PASSES; ++pass) {
+      if (pass > 0) __syncthreads();   // the previous pass's project has read h2
+      // ---- depthwise 3x3 (stride 2) or its transpose on the hidden tile, + bias, ReLU6 (packed half arithmetic)
+      if (pl < NPL) {
+        if (!TR) {
+          for (int po = pl; po < T::POUT; po += NPL) {
+            const int oy = po >> T::LOW, ox = po & (T::OW - 1);
+            const _Float16* src = h1 + ((2 * oy) * T::IW + 2 * ox) * C::HPI + 8 * cg;
+            f16x8 acc = b2r;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx)
+                acc = fma_h8(*reinterpret_cast<const f16x8*>(src + (ky * T::IW + kx) * C::HPI), wdr[3 * ky + kx], acc);
+            *reinterpret_cast<f16x8*>(h2 + po * C::HPI + 8 * cg) = clamp01_h8(acc);
+          }
+        } else {
+          // out[o] += in[i] * w[k] with o = 2i - 1 + k: even outputs take tap 1 of cell i, odd ones tap 2 of i and tap 0 of
+          // i+1; this pass: the cells of row `pass`, i.e. output rows 2 pass and 2 pass + 1 (rows 0 and 1 of h2)
+          for (int cx = pl; cx < T::TW; cx += NPL) {
+            const _Float16* src = h1 + (pass * T::IW + cx) * C::HPI + 8 * cg;
+            const f16x8 v00 = *reinterpret_cast<const f16x8*>(src), v01 = *reinterpret_cast<const f16x8*>(src + C::HPI);
+            const f16x8 v10 = *reinterpret_cast<const f16x8*>(src + T::IW * C::HPI);
+            const f16x8 v11 = *reinterpret_cast<const f16x8*>(src + (T::IW + 1) * C::HPI);
+            const f16x8 o00 = fma_h8(v00, wdr[4], b2r);
+            const f16x8 o01 = fma_h8(v01, wdr[3], fma_h8(v00, wdr[5], b2r));
+            const f16x8 o10 = fma_h8(v10, wdr[1], fma_h8(v00, wdr[7], b2r));
+            const f16x8 o11 = fma_h8(v11, wdr[0], fma_h8(v10, wdr[2], fma_h8(v01, wdr[6], fma_h8(v00, wdr[8], b2r))));
+            _Float16* dst = h2 + (2 * cx) * C::HPI + 8 * cg;
+            *reinterpret_cast<f16x8*>(dst) = clamp01_h8(o00);
+            *reinterpret_cast<f16x8*>(dst + C::HPI) = clamp01_h8(o01);
+            *reinterpret_cast<f16x8*>(dst + T::OW * C::HPI) = clamp01_h8(o10);
+            *reinterpret_cast<f16x8*>(dst + (T::OW + 1) * C::HPI) = clamp01_h8(o11);
+          }
         }
       }
-    }
-    __syncthreads();
-    IR_T(3);
+      __syncthreads();
+      IR_T(3);
 
-    // ---- project: out[pixel][cout] = W3 h2 + b3 (no activation)
-    {
-      f16x8 wa[C::CT][C::KS3];
-#pragma unroll
-      for (int mt = 0; mt < C::CT; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < C::KS3; ++ks) wa[mt][ks] = *reinterpret_cast<const f16x8*>(wf3 + ((mt * C::KS3 + ks) * 64 + lane) * 8);
-      const int oy0 = TR ? 2 * y0 : (y0 + 1) / 2, ox0 = TR ? 2 * x0 : (x0 + 1) / 2;
-      char* ob = static_cast<char*>(a.out) + (size_t)b * a.Ho * a.Wo * COUT * (OUT_F32 ? 4 : 2);
-      for (int nt = wave; nt < T::NT3; nt += 4) {
+      // ---- project: out[pixel][cout] = W3 h2 + b3 (no activation)
+      for (int nt = wave; nt < T::PNT3; nt += 4) {
         const int po = 16 * nt + p;
         f16x8 hb[C::KS3];
 #pragma unroll
         for (int ks = 0; ks < C::KS3; ++ks) hb[ks] = *reinterpret_cast<const f16x8*>(h2 + po * C::HPI + 32 * ks + 8 * q);
-        const int oy = oy0 + (po >> T::LOW), ox = ox0 + (po & (T::OW - 1));
+        const int oy = oy0 + (TR ? 2 * pass : 0) + (po >> T::LOW), ox = ox0 + (po & (T::OW - 1));
         const bool valid = oy < a.Ho && ox < a.Wo;
         const unsigned obase = (unsigned)((oy * a.Wo + ox) * COUT);
 #pragma unroll
         for (int mt = 0; mt < C::CT; ++mt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < C::KS3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[mt][ks], hb[ks], acc, 0, 0, 0);
+          for (int ks = 0; ks < C::KS3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3r[mt][ks], hb[ks], acc, 0, 0, 0);
           const int co = 16 * mt + 4 * q;
           if (valid && co < COUT) {
             if (OUT_F32) {
