@@ -587,7 +587,7 @@ struct TailArgs {
   float bias;
 };
 
-constexpr int TL_CH = 8, TL_CW = 16;
+constexpr int TL_CH = 7, TL_CW = 15;   // the u region is then 8 x 16 = 128 pixels: one depthwise round, eight 16-pixel tiles
 constexpr int TL_UH = TL_CH + 1, TL_UW = TL_CW + 1, TL_PU = TL_UH * TL_UW, TL_NTU = (TL_PU + 15) / 16;   // u region
 constexpr int TL_SH = TL_CH + 3, TL_SW = TL_CW + 3, TL_PS = TL_SH * TL_SW;                                // s region
 constexpr int TL_CP = 32 + 8, TL_SP = 16 + 8;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
   uint4 prd[NIS], prs[NIS];     // raw prefetch registers: D2 and A1 pieces (8 bf16 each), summed when they are stored
   unsigned sin = 0;
   bf16x8 prea[NIA];
-  constexpr int NOUT = 4 * TL_CH * TL_CW, NIO = NOUT / 256;       // outputs of a tile, per thread
+  constexpr int NOUT = 4 * TL_CH * TL_CW, NIO = (NOUT + 255) / 256;       // outputs of a tile, per thread
   float plm[NIO], pmx = 1.f;    // the tile's log-magnitudes and the clip's normaliser, requested with the tile's inputs
   const int ntiles = a.B * a.tiles_y * a.tiles_x;      // < 2^31 (checked by the launcher)
   int nb = 0, ncy0 = 0, ncx0 = 0;                      // origin of the prefetched tile
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
       pmx = a.absmax[b];
 #pragma unroll
       for (int u = 0; u < NIO; ++u) {
-        const int oi = tid + 256 * u, Y = oi / (2 * TL_CW), X = oi - Y * (2 * TL_CW);
+        const int oi = min(tid + 256 * u, NOUT - 1), Y = oi / (2 * TL_CW), X = oi - Y * (2 * TL_CW);
         int y = 2 * cy0 + Y - a.offy, x = 2 * cx0 + X - a.offx;
         y = min(max(y, 0), a.H - 1);
         x = min(max(x, 0), a.W - 1);
@@ -766,7 +766,8 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
     // ---- output samples: the 2CH x 2CW outputs of the tile, 256 at a time
 #pragma unroll
     for (int u = 0; u < NIO; ++u) {
-      const int oi = tid + 256 * u;
+      const bool live = tid + 256 * u < NOUT;
+      const int oi = live ? tid + 256 * u : 0;
       const int Y = oi / (2 * TL_CW), X = oi - Y * (2 * TL_CW);
       const int cy = Y >> 1, dy = Y & 1, cx = X >> 1, dx = X & 1;
       float f = a.bias;
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
           f += on ? v : 0.f;
         }
       const int y = 2 * cy0 + Y - a.offy, x = 2 * cx0 + X - a.offx;
-      if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
+      if (live && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
         const size_t o = ((size_t)b * a.H + y) * a.W + x;
         if (a.filt) a.filt[o] = f;
         if (a.enh) a.enh[o] = fminf(fmaxf(clm[u] / cmx + f, -1.f), 1.f) * cmx;
@@ -839,7 +840,7 @@ NOISE_EXPORT int noise_fused_ir_block(const void* x, const void* skip, int in_f3
   IR_CASE(32, 96, 64, false, 2, false, true)
   IR_CASE(64, 192, 32, true, 2, true, false)
   IR_CASE(32, 96, 24, true, 2, false, false)
-  IR_CASE(24, 72, 16, true, 2, false, false)
+  IR_CASE(24, 72, 16, true, 4, false, false)
 #undef IR_CASE
   NOISE_REQUIRE(done, "noise_fused_ir_block: no fused kernel for %d -> %d -> %d (%s); use the per-layer fp32 path", Cin, Hid,
                 Cout, transposed ? "transposed" : "strided");
