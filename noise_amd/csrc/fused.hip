@@ -92,8 +92,12 @@ struct TileGeom {
 template <int CIN, int HID, int COUT, bool TR, int TH>
 struct IrCfg {
   using G_ = TileGeom<TR, TH>;
-  static constexpr int KP = rup(CIN, 32), KS1 = KP / 32, IP = KP + 8;
-  static constexpr int HT = (HID + 15) / 16, HP = rup(HID, 32), KS3 = HP / 32, HPI = HP + 8, G = (HID + 7) / 8;
+  // MFMA reduction steps cover 32 channels (KP, HP: the padded widths of the weight images); the tiles in LDS only hold
+  // the channels that exist, rounded up to the 8 a lane reads at once (KR, HR): lanes whose 8 channels lie beyond feed
+  // zeros without reading.  The narrower rows are what lets another workgroup fit on a CU.
+  static constexpr int KP = rup(CIN, 32), KS1 = KP / 32, KR = rup(CIN, 8), IP = KR + 8;
+  static constexpr int HT = (HID + 15) / 16, HP = rup(HID, 32), KS3 = HP / 32, HR = rup(HID, 8), HPI = HR + 8, G = (HID + 7) / 8;
+  static_assert(HT * 16 <= HPI, "the expand epilogue writes 16 channels per tile into a row");
   static constexpr int CT = (COUT + 15) / 16;
   static constexpr int LDS_IN = G_::NT1 * 16 * IP, LDS_H1 = G_::NT1 * 16 * HPI, LDS_H2 = G_::PPOUT * HPI;   // halves
   static constexpr int LDS_W1 = HT * KS1 * 64 * 8, LDS_W3 = CT * KS3 * 64 * 8;                             // halves
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
         const int pi = 16 * nt + p;
         f16x8 xv[C::KS1];
 #pragma unroll
-        for (int ks = 0; ks < C::KS1; ++ks) xv[ks] = *reinterpret_cast<const f16x8*>(in_t + pi * C::IP + 32 * ks + 8 * q);
+        for (int ks = 0; ks < C::KS1; ++ks)
+          xv[ks] = 32 * ks + 8 * q < C::KR ? *reinterpret_cast<const f16x8*>(in_t + pi * C::IP + 32 * ks + 8 * q) : f16x8{};
         const float m = maskf[pi];
         const bool inside = __all(m != 0.f);
 #pragma unroll
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
             o[2] = (_Float16)(clamp01(acc[2] + bb.z) * m);
             o[3] = (_Float16)(clamp01(acc[3] + bb.w) * m);
           }
-          *reinterpret_cast<f16x4*>(h1 + pi * C::HPI + 16 * mt + 4 * q) = o;   // HT*16 <= HP: inside the row
+          *reinterpret_cast<f16x4*>(h1 + pi * C::HPI + 16 * mt + 4 * q) = o;   // HT*16 <= HPI: inside the row
         }
       }
     }
@@ -329,7 +334,8 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
         const int po = 16 * nt + p;
         f16x8 hb[C::KS3];
 #pragma unroll
-        for (int ks = 0; ks < C::KS3; ++ks) hb[ks] = *reinterpret_cast<const f16x8*>(h2 + po * C::HPI + 32 * ks + 8 * q);
+        for (int ks = 0; ks < C::KS3; ++ks)
+          hb[ks] = 32 * ks + 8 * q < C::HR ? *reinterpret_cast<const f16x8*>(h2 + po * C::HPI + 32 * ks + 8 * q) : f16x8{};
         const int oy = oy0 + (TR ? 2 * pass : 0) + (po >> T::LOW), ox = ox0 + (po & (T::OW - 1));
         const bool valid = oy < a.Ho && ox < a.Wo;
         const unsigned obase = (unsigned)((oy * a.Wo + ox) * COUT);
