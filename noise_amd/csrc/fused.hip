@@ -102,7 +102,12 @@ struct IrCfg {
   static constexpr int LDS_IN = G_::NT1 * 16 * IP, LDS_H1 = G_::NT1 * 16 * HPI, LDS_H2 = G_::PPOUT * HPI;   // halves
   static constexpr int LDS_W1 = HT * KS1 * 64 * 8, LDS_W3 = CT * KS3 * 64 * 8;                             // halves
   static constexpr int LDS_F = HT * 16 + G_::NT1 * 16;                                                     // floats: b1, pixel mask
-  static constexpr size_t LDS_BYTES = (size_t)(LDS_IN + LDS_H1 + LDS_H2 + LDS_W1 + LDS_W3) * 2 + (size_t)LDS_F * 4;
+  // The depthwise tile may live where the input tile was (dead once the expand has read it) at the price of one more
+  // barrier per tile: done exactly when that buys another resident workgroup (160 KiB of LDS per CU).
+  static constexpr size_t BYTES_SEP = (size_t)(LDS_IN + LDS_H1 + LDS_H2 + LDS_W1 + LDS_W3) * 2 + (size_t)LDS_F * 4;
+  static constexpr bool ALIAS_H2 = LDS_H2 <= LDS_IN && 163840 / (BYTES_SEP - 2 * LDS_H2) > 163840 / BYTES_SEP;
+  static constexpr int OFF_H2 = ALIAS_H2 ? 0 : LDS_IN + LDS_H1, OFF_W1 = LDS_IN + LDS_H1 + (ALIAS_H2 ? 0 : LDS_H2);
+  static constexpr size_t LDS_BYTES = BYTES_SEP - (ALIAS_H2 ? 2 * LDS_H2 : 0);
 };
 
 template <int CIN, int HID, int COUT, bool TR, int TH, bool IN_F32, bool OUT_F32>
@@ -112,15 +117,15 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* in_t = reinterpret_cast<_Float16*>(lds_raw);   // [NT1*16][IP]
   _Float16* h1 = in_t + C::LDS_IN;                          // [NT1*16][HPI]  expand output (zero outside the image)
-  _Float16* h2 = h1 + C::LDS_H1;                            // [PPOUT][HPI]   depthwise output (one pass)
-  _Float16* wf1 = h2 + C::LDS_H2;                           // [HT][KS1][64][8] A fragments of the expand weights
+  _Float16* h2 = in_t + C::OFF_H2;                          // [PPOUT][HPI]   depthwise output (one pass)
+  _Float16* wf1 = in_t + C::OFF_W1;                         // [HT][KS1][64][8] A fragments of the expand weights
   _Float16* wf3 = wf1 + C::LDS_W1;                          // [CT][KS3][64][8]
   float* b1s = reinterpret_cast<float*>(wf3 + C::LDS_W3);   // [HT*16]
   float* maskf = b1s + C::HT * 16;                          // [NT1*16]  1 inside the image, 0 outside
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
 
   // ---- one-time set-up: zero the tiles (padding channels / pixels stay zero for ever), stage weight fragments
-  for (int i = tid; i < (C::LDS_IN + C::LDS_H1 + C::LDS_H2) / 8; i += 256)
+  for (int i = tid; i < C::OFF_W1 / 8; i += 256)
     reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < C::HT * C::KS1 * 64; i += 256) {
     const int l = i & 63, f = i >> 6, ks = f % C::KS1, mt = f / C::KS1;
@@ -359,7 +364,9 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
         }
       }
     }
-    // the next iteration's first barrier separates this tile's reads of h2 / in_t from their next writes
+    // the next iteration's first barrier separates this tile's reads of h2 / in_t from their next writes, unless h2 lives
+    // in the input tile, which the next iteration's staging overwrites before that barrier
+    if (C::ALIAS_H2) __syncthreads();
   }
 }
 
