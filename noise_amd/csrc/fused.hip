@@ -605,7 +605,7 @@ constexpr int TL_UH = TL_CH + 1, TL_UW = TL_CW + 1, TL_PU = TL_UH * TL_UW, TL_NT
 constexpr int TL_SH = TL_CH + 3, TL_SW = TL_CW + 3, TL_PS = TL_SH * TL_SW;                                // s region
 constexpr int TL_CP = 32 + 8, TL_SP = 16 + 8;
 
-__global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(256, 4) void tail_kernel(TailArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 st[TL_PS * TL_SP];          // s = D2 + A1 (zero outside the image)
   __shared__ __attribute__((aligned(16))) __bf16 a0t[TL_NTU * 16 * TL_CP];     // A0 on the u region
   // depthwise output (channels 0..15; the 1x1 weights of channels 16..31 are zero) and, in the same rows once a wave has
@@ -618,10 +618,10 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
   unsigned long long last_ = clock64();
 #endif
   const int cg = tid & 1, pl = tid >> 1;      // depthwise: 2 channel groups of 8, 128 pixel lanes
-  f16x8 wdr[9], b2r;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wdr[k] = *reinterpret_cast<const f16x8*>(a.wd + k * 16 + 8 * cg);
-  b2r = *reinterpret_cast<const f16x8*>(a.b2 + 8 * cg);
+  // the depthwise taps sit in LDS: a thread needs them for one pixel per tile, and 36 registers less is a fourth workgroup
+  __shared__ __attribute__((aligned(16))) _Float16 wds[10 * 16];
+  if (tid < 18) *reinterpret_cast<f16x8*>(wds + 8 * tid) = *reinterpret_cast<const f16x8*>(a.wd + 8 * tid);
+  else if (tid < 20) *reinterpret_cast<f16x8*>(wds + 8 * tid) = *reinterpret_cast<const f16x8*>(a.b2 + 8 * (tid - 18));   // row 9: the bias
   f16x8 w3a[2], wla;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) w3a[mt] = *reinterpret_cast<const f16x8*>(a.w3 + (16 * mt + p) * 32 + 8 * q);
@@ -737,12 +737,13 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(TailArgs a) {
     for (int pu = pl; pu < TL_PU; pu += 128) {
       const int uy = pu / TL_UW, ux = pu - uy * TL_UW;      // u pixel = region origin + (uy, ux); s index = +1
       const _Float16* src = st + ((uy + 2) * TL_SW + ux + 2) * TL_SP + 8 * cg;
-      f16x8 acc = b2r;
+      f16x8 acc = *reinterpret_cast<const f16x8*>(wds + 144 + 8 * cg);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-          acc = fma_h8(*reinterpret_cast<const f16x8*>(src - (ky * TL_SW + kx) * TL_SP), wdr[3 * ky + kx], acc);
+          acc = fma_h8(*reinterpret_cast<const f16x8*>(src - (ky * TL_SW + kx) * TL_SP),
+                       *reinterpret_cast<const f16x8*>(wds + (3 * ky + kx) * 16 + 8 * cg), acc);
       *reinterpret_cast<f16x8*>(h2 + pu * TL_CP + 8 * cg) = clamp01_h8(acc);
     }
     __syncthreads();
