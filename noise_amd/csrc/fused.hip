@@ -414,22 +414,22 @@ struct HeadArgs {
   float pad_value;
 };
 
-constexpr int HD_OH = 16, HD_OW = 16;
+constexpr int HD_OH = 12, HD_OW = 16;   // the A0 halo tile is then 14 x 18 = 252 pixels: 16 MFMA tiles, no idle round
 constexpr int HD_AH = HD_OH + 2, HD_AW = HD_OW + 2, HD_PA = HD_AH * HD_AW, HD_NTA = (HD_PA + 15) / 16;   // A0 halo tile
 constexpr int HD_XH = 2 * HD_AH + 1, HD_XW = 2 * HD_AW + 1, HD_XP = HD_XW + 1, HD_NX = HD_XH * HD_XW;     // input tile
 constexpr int HD_C0 = 32, HD_C1 = 16, HD_CP = HD_C0 + 8;
 constexpr int HD_POUT = HD_OH * HD_OW, HD_NT3 = HD_POUT / 16;
 
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, 4) void head_kernel(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[HD_XH * HD_XP];
   __shared__ __attribute__((aligned(16))) _Float16 h1[HD_NTA * 16 * HD_CP];   // A0 on the halo tile (zero outside the image)
   __shared__ __attribute__((aligned(16))) _Float16 h2[HD_POUT * HD_CP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
   const int cg = tid & 3, pl = tid >> 2;      // depthwise: 4 channel groups of 8, 64 pixel lanes
-  f16x8 wdr[9], b2r;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wdr[k] = *reinterpret_cast<const f16x8*>(a.wd + k * HD_C0 + 8 * cg);
-  b2r = *reinterpret_cast<const f16x8*>(a.b2 + 8 * cg);
+  // the depthwise taps (rows 0..8) and bias (row 9) sit in LDS: 36 registers less is a fourth workgroup per CU
+  __shared__ __attribute__((aligned(16))) _Float16 wds[10 * HD_C0];
+  if (tid < 36) *reinterpret_cast<f16x8*>(wds + 8 * tid) = *reinterpret_cast<const f16x8*>(a.wd + 8 * tid);
+  else if (tid < 40) *reinterpret_cast<f16x8*>(wds + 8 * tid) = *reinterpret_cast<const f16x8*>(a.b2 + 8 * (tid - 36));
   f16x8 w0a[2], w3a;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) w0a[mt] = *reinterpret_cast<const f16x8*>(a.w0 + (16 * mt + p) * 32 + 8 * q);
@@ -550,12 +550,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     for (int po = pl; po < HD_POUT; po += 64) {
       const int oy = po >> 4, ox = po & 15;
       const _Float16* src = h1 + (oy * HD_AW + ox) * HD_CP + 8 * cg;
-      f16x8 acc = b2r;
+      f16x8 acc = *reinterpret_cast<const f16x8*>(wds + 9 * HD_C0 + 8 * cg);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-          acc = fma_h8(*reinterpret_cast<const f16x8*>(src + (ky * HD_AW + kx) * HD_CP), wdr[3 * ky + kx], acc);
+          acc = fma_h8(*reinterpret_cast<const f16x8*>(src + (ky * HD_AW + kx) * HD_CP),
+                       *reinterpret_cast<const f16x8*>(wds + (3 * ky + kx) * HD_C0 + 8 * cg), acc);
       *reinterpret_cast<f16x8*>(h2 + po * HD_CP + 8 * cg) = clamp01_h8(acc);
     }
     __syncthreads();
