@@ -216,14 +216,19 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
     }
   };
 
-  // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
-  int tile = xcd_chunked_block();
-  if (tile < ntiles) prefetch(tile);
+  // Neighbouring tiles share halo pixels and partial cache lines.  XCD j (workgroups j, j + 8, ...: one L2) owns the
+  // contiguous tile range [j T8, (j + 1) T8) and its workgroups stride through it together, so the window of tiles in
+  // flight on an L2 advances row by row through one clip after the other and the halo rows of a window are still in
+  // that L2 when the next window needs them.
+  const int T8 = (ntiles + 7) >> 3, tstep = (int)(gridDim.x >> 3);
+  const int tend = min(ntiles, (int)((blockIdx.x & 7u) + 1) * T8);
+  int tile = (int)(blockIdx.x & 7u) * T8 + (int)(blockIdx.x >> 3);
+  if (tile < tend) prefetch(tile);
   __syncthreads();
 #ifdef FUSED_STAMPS
   unsigned long long last_ = clock64();
 #endif
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < tend; tile += tstep) {
     const int b = nb, y0 = ny0, x0 = nx0;
     IR_T(5);
     // ---- registers -> input tile (+ the pixel mask, written by the thread that holds a pixel's first piece)
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrArgs a) {
     }
     __syncthreads();
     IR_T(0);
-    if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    if (tile + tstep < tend) prefetch(tile + tstep);
     IR_T(1);
 
     // ---- expand: h1[pixel][hidden] = relu6(W1 x + b1), zero outside the image (the depthwise padding)
@@ -484,14 +489,19 @@ __global__ __launch_bounds__(256, 4) void head_kernel(HeadArgs a) {
       finside |= inside ? (1u << u) : 0u;
     }
   };
-  // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
-  int tile = xcd_chunked_block();
-  if (tile < ntiles) prefetch(tile);
+  // Neighbouring tiles share halo pixels and partial cache lines.  XCD j (workgroups j, j + 8, ...: one L2) owns the
+  // contiguous tile range [j T8, (j + 1) T8) and its workgroups stride through it together, so the window of tiles in
+  // flight on an L2 advances row by row through one clip after the other and the halo rows of a window are still in
+  // that L2 when the next window needs them.
+  const int T8 = (ntiles + 7) >> 3, tstep = (int)(gridDim.x >> 3);
+  const int tend = min(ntiles, (int)((blockIdx.x & 7u) + 1) * T8);
+  int tile = (int)(blockIdx.x & 7u) * T8 + (int)(blockIdx.x >> 3);
+  if (tile < tend) prefetch(tile);
   __syncthreads();
 #ifdef FUSED_STAMPS
   unsigned long long last_ = clock64();
 #endif
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < tend; tile += tstep) {
     const int b = nb, oy0 = noy0, ox0 = nox0;
     FU_T(13);
     {
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(256, 4) void head_kernel(HeadArgs a) {
     }
     __syncthreads();
     FU_T(8);
-    if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    if (tile + tstep < tend) prefetch(tile + tstep);
     FU_T(9);
 
     // ---- first conv on the A0 halo tile
@@ -701,12 +711,17 @@ __global__ __launch_bounds__(256, 4) void tail_kernel(TailArgs a) {
       }
     }
   };
-  // neighbouring tiles share halo pixels and partial cache lines: consecutive tile indices run on one XCD (one L2)
-  int tile = xcd_chunked_block();
-  if (tile < ntiles) prefetch(tile);
+  // Neighbouring tiles share halo pixels and partial cache lines.  XCD j (workgroups j, j + 8, ...: one L2) owns the
+  // contiguous tile range [j T8, (j + 1) T8) and its workgroups stride through it together, so the window of tiles in
+  // flight on an L2 advances row by row through one clip after the other and the halo rows of a window are still in
+  // that L2 when the next window needs them.
+  const int T8 = (ntiles + 7) >> 3, tstep = (int)(gridDim.x >> 3);
+  const int tend = min(ntiles, (int)((blockIdx.x & 7u) + 1) * T8);
+  int tile = (int)(blockIdx.x & 7u) * T8 + (int)(blockIdx.x >> 3);
+  if (tile < tend) prefetch(tile);
   __syncthreads();
   FU_T(0);
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < tend; tile += tstep) {
     const int b = nb, cy0 = ncy0, cx0 = ncx0;
     FU_T(6);
 #pragma unroll
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(256, 4) void tail_kernel(TailArgs a) {
     const float cmx = pmx + 1e-6f;
     __syncthreads();
     FU_T(1);
-    if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    if (tile + tstep < tend) prefetch(tile + tstep);
     FU_T(2);
 
     // ---- depthwise ConvTranspose2d 3x3 stride 1: out[o] = sum_k s[o + 1 - k] w[k]
