@@ -37,11 +37,7 @@ __device__ __forceinline__ CvLane cv_lane(int C, int cl) {
   return r;
 }
 
-// per-channel partial sums of a block -> one slab row ([sum(C) | sum of squares(C)]); every thread of the block calls it.
-// The sums are fp32 per workgroup and folded in double, so the variance E[y^2] - E[y]^2 carries the rounding of the fp32
-// squares: about 6e-8 (mean^2 + var) absolute.  That is far below BatchNorm's eps for activations whose spread is
-// comparable to their mean; a channel that holds only a handful of nearly equal samples (a 1 x 2 image at the bottom of
-// the U with a batch of one) gets fewer correct digits of variance than torch's two-pass kernel.
+// per-channel partial sums of a block -> one slab row ([sum(C) | sum of squares(C)]); every thread of the block calls it
 __device__ __forceinline__ void cv_stats(const CvLane& L, int C, int cl, float4 s1, float4 s2, float* __restrict__ slab) {
   __shared__ float red[256 * 8];
   float* mine = red + threadIdx.x * 8;
