@@ -89,7 +89,10 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
   c32* tw1 = zbuf + FR * ZP;                                // [N2]
   c32* tw2 = tw1 + N2;                                      // [N2 + 1]
   float* wn = reinterpret_cast<float*>(tw2 + N2 + 1);       // [N]
-  float* xs = wn + N;                                       // [(FR-1) hop + N]
+  // The staged samples [(FR-1) hop + N] share the complex buffer: pass A reads its samples into registers, a barrier, and
+  // only then writes its results over them.  One buffer less is another resident workgroup per CU.
+  float* xs = reinterpret_cast<float*>(lds_raw);
+  static_assert((size_t)FR * N * 4 <= FftLds<N2, FR>::zbytes, "the staged samples must fit in the complex buffer");
   const int tid = threadIdx.x;
 #ifdef FFT_STAMPS
   unsigned long long last_ = clock64();
@@ -162,14 +165,17 @@ __global__ __launch_bounds__(16 * FR) void stft_fft_kernel(const float* __restri
   const int fr = tid >> 4, j = tid & 15;
   c32* zrow = zbuf + fr * ZP;
   // ---- pass A
+  c32 v[R2];
   if (j < R1) {
     const float* x = xs + fr * hop;
-    c32 v[R2];
 #pragma unroll
     for (int m2 = 0; m2 < R2; ++m2) {
       const int n = 2 * (j + R1 * m2);
       v[m2] = {x[n] * wn[n], x[n + 1] * wn[n + 1]};
     }
+  }
+  __syncthreads();   // every frame has its samples: the complex buffer may overwrite them
+  if (j < R1) {
     Dft<R2>::run(v);
     zrow[j * R2] = v[0];
 #pragma unroll
@@ -476,7 +482,8 @@ __global__ __launch_bounds__(256) void stft_absmax_refine_kernel(const float* __
 
 template <int N2, int FR>
 size_t fwd_smem(int hop) {
-  return FftLds<N2, FR>::zbytes + (size_t)(N2 + N2 + 1) * 8 + (size_t)(2 * N2) * 4 + (size_t)((FR - 1) * hop + 2 * N2) * 4;
+  (void)hop;   // the staged samples ((FR-1) hop + N floats) live inside the complex buffer
+  return FftLds<N2, FR>::zbytes + (size_t)(N2 + N2 + 1) * 8 + (size_t)(2 * N2) * 4;
 }
 template <int N2, int FR>
 size_t inv_smem() {
