@@ -491,7 +491,7 @@ size_t inv_smem() {
 }
 
 #ifndef FWD_FR_320
-#define FWD_FR_320 32
+#define FWD_FR_320 16
 #endif
 #ifndef FWD_FR_512
 #define FWD_FR_512 16
