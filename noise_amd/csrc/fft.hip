@@ -496,7 +496,7 @@ size_t inv_smem() {
 #ifndef FWD_FR_512
 #define FWD_FR_512 16
 #endif
-constexpr int INV_FR = 32;   // frames per workgroup: 32 consecutive frames of one bin are one 128-byte line of [B][F][T]
+constexpr int INV_FR = 16;   // frames per workgroup (measured: 32, one 128-byte line of [B][F][T] per bin, is equal at n_fft 320 and 7 % slower at 512, where it leaves two workgroups per CU)
 
 template <int MODE, bool FAST>
 int launch_fwd(int n_fft, const float* sig, const float* win, const float* tw1, const float* tw2, float* out0, float* out1,
