@@ -19,13 +19,18 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 struct Attn16Dims {
   long ntok;
   int n, heads, dk, hd, n32, vp;   // n32 = n rounded up to the 64 keys of a step; vp = row pitch of V^T (halves)
+  int kp, vrows;                   // columns of K kept in LDS (d_k rounded up to 4), rows of V^T kept (d_k + the ones row)
 };
 
+// KP / VROWS: columns of K and rows of V^T kept in LDS, compile-time so that the operand loads below do not branch
+template <int KP, int VROWS>
 __global__ __launch_bounds__(1024) void attn_core_f16_kernel(const float* __restrict__ qkv, float* __restrict__ o, Attn16Dims d,
                                                             int nsplit, int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  _Float16* ks = reinterpret_cast<_Float16*>(lds_raw);   // [n32][16], rows >= n and columns >= d_k zero
-  _Float16* vt = ks + (size_t)d.n32 * 16;                 // [16][vp], V transposed, zero padded
+  // Only what exists is kept: the lanes of an MFMA operand whose columns / rows lie beyond feed zeros without reading, and
+  // a 10 s clip at hop 128 then takes 65 KB instead of 90 KB, i.e. two workgroups per CU instead of one.
+  _Float16* ks = reinterpret_cast<_Float16*>(lds_raw);   // [n32][kp], rows >= n and columns >= d_k zero
+  _Float16* vt = ks + (size_t)d.n32 * KP;               // [vrows][vp], V transposed, zero padded, row d_k all ones
   const int n = d.n, dk = d.dk, O = 3 * d.hd;
   // the splits of a (clip, head) restage the same K/V and the heads of a clip share every 32-byte sector of its qkv
   // rows: consecutive virtual indices run on one XCD, so those bytes come from HBM once, not once per L2
@@ -40,9 +45,9 @@ __global__ __launch_bounds__(1024) void attn_core_f16_kernel(const float* __rest
     const bool in = j < n && c < dk;
     const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : dk - 1);
     const float kv = row[d.hd], vv = row[2 * d.hd];
-    ks[i] = (_Float16)(in ? kv : 0.f);
+    if (c < KP) ks[j * KP + c] = (_Float16)(in ? kv : 0.f);
     // row d_k of V^T is all ones over the real keys: the P V product then carries sum_j p_j in output row d_k
-    vt[c * d.vp + j] = (_Float16)(in ? vv : ((c == dk && j < n) ? 1.f : 0.f));   // (d_k = 16 leaves no spare row)
+    if (c < VROWS) vt[c * d.vp + j] = (_Float16)(in ? vv : ((c == dk && j < n) ? 1.f : 0.f));   // (d_k = 16 leaves no spare row)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
@@ -62,8 +67,8 @@ __global__ __launch_bounds__(1024) void attn_core_f16_kernel(const float* __rest
       f16x4 ka[4], va[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        ka[g] = *reinterpret_cast<const f16x4*>(ks + (key0 + 16 * g + p) * 16 + 4 * q);
-        va[g] = *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 16 * g + 4 * q);
+        ka[g] = 4 * q < KP ? *reinterpret_cast<const f16x4*>(ks + (key0 + 16 * g + p) * KP + 4 * q) : f16x4{};
+        va[g] = p < VROWS ? *reinterpret_cast<const f16x4*>(vt + p * d.vp + key0 + 16 * g + 4 * q) : f16x4{};
       }
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       f32x4 sv[4];
@@ -137,9 +142,17 @@ NOISE_EXPORT int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, 
   NOISE_REQUIRE(heads > 0 && dk > 0 && dk <= 16 && heads * dk <= d_model, "noise_attn_core_fwd_f16: heads=%d d_k=%d unsupported",
                 heads, dk);
   NOISE_REQUIRE(n > 0 && ntok > 0 && ntok % n == 0, "noise_attn_core_fwd_f16: %ld tokens is not a multiple of n=%d", ntok, n);
-  Attn16Dims d{ntok, n, heads, dk, heads * dk, (n + 63) / 64 * 64, 0};
+  Attn16Dims d{ntok, n, heads, dk, heads * dk, (n + 63) / 64 * 64, 0, 0, 0};
   d.vp = d.n32 + 8;
-  const size_t smem = ((size_t)d.n32 * 16 + (size_t)16 * d.vp) * sizeof(_Float16);
+  // The reference configuration (d_k = 64 // 6 = 10) may keep K as [n][12] and V^T as 11 rows.  The narrow rows cost bank
+  // conflicts (measured 0.18 -> 0.23 ms where nothing else changes), so they are used exactly when they let a second
+  // workgroup onto the CU (10 s clips at hop 128: 90 KB -> 65 KB, 0.76 -> 0.66 ms).
+  const size_t full_bytes = ((size_t)d.n32 * 16 + (size_t)16 * d.vp) * sizeof(_Float16);
+  const size_t compact_bytes = ((size_t)d.n32 * 12 + (size_t)11 * d.vp) * sizeof(_Float16);
+  const bool compact = dk == 10 && full_bytes > 80 * 1024 && compact_bytes <= 80 * 1024;
+  d.kp = compact ? 12 : 16;
+  d.vrows = compact ? 11 : 16;
+  const size_t smem = ((size_t)d.n32 * d.kp + (size_t)d.vrows * d.vp) * sizeof(_Float16);
   NOISE_REQUIRE(smem <= 158 * 1024, "noise_attn_core_fwd_f16: n=%d tokens per clip exceed the LDS-resident K/V limit", n);
   const long bh = (ntok / n) * heads;
   const int threads = smem > 32 * 1024 ? 1024 : 256, nw = threads / 64;
@@ -147,10 +160,15 @@ NOISE_EXPORT int noise_attn_core_fwd_f16(const float* qkv, float* o, long ntok, 
   const int max_split = ((n + 15) / 16 + nw - 1) / nw;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
-  NOISE_ALLOW_LDS(attn_core_f16_kernel, smem);
   const int total = (int)(bh * nsplit);
-  hipLaunchKernelGGL(attn_core_f16_kernel, dim3((unsigned)noise_pad8(total)), dim3(threads), smem, (hipStream_t)stream, qkv, o, d,
-                     nsplit, total);
+  const dim3 grid((unsigned)noise_pad8(total));
+  if (compact) {
+    NOISE_ALLOW_LDS((attn_core_f16_kernel<12, 11>), smem);
+    hipLaunchKernelGGL((attn_core_f16_kernel<12, 11>), grid, dim3(threads), smem, (hipStream_t)stream, qkv, o, d, nsplit, total);
+  } else {
+    NOISE_ALLOW_LDS((attn_core_f16_kernel<16, 16>), smem);
+    hipLaunchKernelGGL((attn_core_f16_kernel<16, 16>), grid, dim3(threads), smem, (hipStream_t)stream, qkv, o, d, nsplit, total);
+  }
   NOISE_CHECK_LAUNCH("noise_attn_core_fwd_f16");
   return 0;
 }
