@@ -312,10 +312,18 @@ int launch_virt(LazySrc In, const float* wdw, LazySrc Dw, const float* W, float*
 //      weight gradient dW += dy^T a over the 64 pixels from the activated tile.
 // The next tile's global loads are requested right after the staging barrier and stay in registers through the MFMAs.
 constexpr int virt_bwd_pitch(int tiles) { return tiles * 16 + 4; }
+// LEAN (the 72 -> 16 instance, more than half of the family's time): three workgroups per CU instead of two.  The
+// activated tile is not kept in LDS (it is one multiply-add and a clamp away from the raw tile) and the per-lane
+// coefficient vectors of the epilogue stay in LDS instead of registers: the kernel lives on memory parallelism, and a
+// third resident workgroup is worth more than the LDS reads it costs.
+constexpr bool virt_bwd_lean(int KC, int MTI) { return KC == 1 && MTI == 5; }
 constexpr int virt_bwd_lds_floats(int KC, int MTI) {
-  return MTI * KC * 256 + 64 * virt_bwd_pitch(KC) + 2 * 64 * virt_bwd_pitch(MTI) + 17 * MTI * 16;
+  return MTI * KC * 256 + 64 * virt_bwd_pitch(KC) + (virt_bwd_lean(KC, MTI) ? 1 : 2) * 64 * virt_bwd_pitch(MTI) + 17 * MTI * 16 +
+         (virt_bwd_lean(KC, MTI) ? 6 * KC * 16 : 0);
 }
-constexpr int virt_bwd_min_blocks(int KC, int MTI) { return virt_bwd_lds_floats(KC, MTI) * 8 <= 160 * 1024 ? 2 : 1; }
+constexpr int virt_bwd_min_blocks(int KC, int MTI) {
+  return virt_bwd_lean(KC, MTI) ? 3 : (virt_bwd_lds_floats(KC, MTI) * 8 <= 160 * 1024 ? 2 : 1);
+}
 
 template <int KC, int MTI>
 __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd_kernel(
@@ -330,10 +338,12 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
   constexpr int pn = virt_bwd_pitch(KC), pk = virt_bwd_pitch(MTI);
   float* wfrag = lds;                       // [MTI][KC][64][4] fragment image of W for the input gradient
   float* dys = wfrag + MTI * KC * 256;      // [64][pn] dy, row 16 * parity + cell
-  float* as = dys + 64 * pn;                // [64][pk] activated depthwise output
-  float* raws = as + 64 * pk;               // [64][pk] raw depthwise output
+  constexpr bool LEAN = virt_bwd_lean(KC, MTI);
+  float* as = dys + 64 * pn;                // [64][pk] activated depthwise output (not kept when LEAN)
+  float* raws = LEAN ? as : as + 64 * pk;   // [64][pk] raw depthwise output
   float* cf = raws + 64 * pk;               // [7][KP]: source scale, shift; depthwise scale, shift, mean, invstd, mean_lo
   float* wt = cf + 7 * KP;                  // [10][KP]: the 9 taps, row 9 unused
+  float* gcf = wt + 10 * KP;                // [6][NP] (LEAN): the lazy-gradient coefficients of the projection's BatchNorm
   if ((N & 15) || (K & 15)) {
     for (int idx = tid; idx < MTI * KC * 256; idx += 256) wfrag[idx] = 0.f;
     __syncthreads();
@@ -383,7 +393,12 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
   const int cn = (tid % CGN) * 4, in_cell = (tid / CGN) & 15, jn0 = tid / (CGN * 16);
   const bool on = cn < N;
   float4 gs = f4(1.f), gk1h = f4(0.f), gk1l = f4(0.f), ga2 = f4(0.f), gmh = f4(0.f), gml = f4(0.f);
-  if (on && G.coef3) {
+  if (LEAN) {      // the six vectors go to LDS (read back per tile) instead of 24 registers
+    for (int k = tid; k < 6 * NP; k += 256) {
+      const int r = k / NP, c = k - r * NP;
+      gcf[k] = (c < N && G.coef3) ? G.coef3[r * N + c] : (r == 0 ? 1.f : 0.f);
+    }
+  } else if (on && G.coef3) {
     gs = ld4(G.coef3 + cn);
     gk1h = ld4(G.coef3 + N + cn);
     gk1l = ld4(G.coef3 + 2 * N + cn);
@@ -438,9 +453,15 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
   // The input-gradient epilogue of a lane always works on the same channels (16 m2 + 4 q .. + 3): with few channel tiles
   // its three coefficient vectors per tile stay in registers instead of being read from LDS for every pixel (the LDS
   // pipe, not memory, bounds this kernel).
-  constexpr bool EPI_REGS = MTI <= 5;
+  constexpr bool EPI_REGS = MTI <= 5 && !LEAN;
   float4 e_mean[EPI_REGS ? MTI : 1], e_mlo[EPI_REGS ? MTI : 1], e_istd[EPI_REGS ? MTI : 1];
   __syncthreads();   // the tables are written
+  float wsc[TPW], wsh[TPW];      // LEAN: depthwise BatchNorm scale / shift of the channel this lane feeds to each dW tile
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    wsc[j] = LEAN ? cf[2 * KP + avo[j]] : 1.f;
+    wsh[j] = LEAN ? cf[3 * KP + avo[j]] : 0.f;
+  }
   constexpr bool WF_REGS = EPI_REGS && KC == 1;   // the lane's weight fragments of the input gradient as well
   float4 wf[WF_REGS ? MTI : 1];
   if (EPI_REGS) {
@@ -461,7 +482,11 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
     for (int u = 0; u < PASS_N; ++u) {
       const int pp = 16 * (jn0 + JP * u) + in_cell;
       float4 v = rz[u];
-      if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
+      if (LEAN) {
+        if (G.coef3)
+          v = fma4(ld4(gcf + 3 * NP + cn), sub4(sub4(ry[u], ld4(gcf + 4 * NP + cn)), ld4(gcf + 5 * NP + cn)),
+                   ld4(gcf + cn) * sub4(sub4(v, ld4(gcf + NP + cn)), ld4(gcf + 2 * NP + cn)));
+      } else if (G.coef3) v = fma4(ga2, sub4(sub4(ry[u], gmh), gml), gs * sub4(sub4(v, gk1h), gk1l));
       st4(dys + pp * pn + cn, (on && ((nflag >> u) & 1)) ? v : f4(0.f));
     }
 #pragma unroll
@@ -486,7 +511,7 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           st4(raws + (16 * j + ci) * pk + ck, y[j]);
-          st4(as + (16 * j + ci) * pk + ck, clamp4(fma4(y[j], dsc, dsh), dlo, dhi));
+          if (!LEAN) st4(as + (16 * j + ci) * pk + ck, clamp4(fma4(y[j], dsc, dsh), dlo, dhi));
         }
       }
     }
@@ -520,7 +545,8 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
           float4 g = make_float4(o[0], o[1], o[2], o[3]);
           const float4 yraw = ld4(raws + (16 * wave + p) * pk + ci);
           if (dw_relu6) {   // the clamped activation is strictly inside (0, 6) exactly where the ReLU6 passes gradient
-            const float4 v = ld4(as + (16 * wave + p) * pk + ci);
+            const float4 v = LEAN ? clamp4(fma4(yraw, ld4(cf + 2 * KP + ci), ld4(cf + 3 * KP + ci)), dlo, dhi)
+                                  : ld4(as + (16 * wave + p) * pk + ci);
             g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
             g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
             g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
@@ -539,8 +565,10 @@ __global__ __launch_bounds__(256, virt_bwd_min_blocks(KC, MTI)) void pw_virt_bwd
     for (int s = 0; s < 16; ++s) {
       const int pp = 4 * s + q;
 #pragma unroll
-      for (int j = 0; j < TPW; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], as[pp * pk + avo[j]], acc[j], 0, 0, 0);
+      for (int j = 0; j < TPW; ++j) {
+        const float av = LEAN ? __builtin_amdgcn_fmed3f(fmaf(raws[pp * pk + avo[j]], wsc[j], wsh[j]), dlo, dhi) : as[pp * pk + avo[j]];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dys[pp * pn + dyo[j]], av, acc[j], 0, 0, 0);
+      }
     }
   }
 
