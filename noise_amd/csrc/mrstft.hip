@@ -34,7 +34,8 @@ struct MrCfg {
   static constexpr int NT = ROWS * TPF;
   static constexpr int ZP = N2 + 1;
   static size_t smem(int hop) {
-    return (size_t)ROWS * ZP * 8 + (size_t)(N2 + N2 + 1) * 8 + (size_t)(2 * N2) * 4 + (size_t)2 * ((FR - 1) * hop + 2 * N2) * 4;
+    (void)hop;   // the staged samples live inside the complex buffer
+    return (size_t)ROWS * ZP * 8 + (size_t)(N2 + N2 + 1) * 8 + (size_t)(2 * N2) * 4;
   }
 };
 
@@ -75,7 +76,10 @@ __global__ __launch_bounds__((MrCfg<N2, R1, R2, FR>::NT)) void mrstft_frames_ker
   c32* tw1 = zbuf + ROWS * ZP;                              // [N2]      e^{-2 pi i j / N2}
   c32* tw2 = tw1 + N2;                                      // [N2 + 1]  e^{-2 pi i k / N}
   float* wn = reinterpret_cast<float*>(tw2 + N2 + 1);       // [N]
-  float* xs = wn + N;                                       // [2][(FR-1) hop + N]
+  // the staged samples [2][(FR-1) hop + N] share the complex buffer: pass A reads its samples into registers, a barrier,
+  // and only then writes over them (one buffer less is a second resident workgroup at n_fft 512 and 1024)
+  float* xs = reinterpret_cast<float*>(lds_raw);
+  static_assert((size_t)2 * FR * N * 4 <= (size_t)ROWS * ZP * 8, "the staged samples must fit in the complex buffer");
   __shared__ double red[NT / 64];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, t0 = blockIdx.x * FR;
@@ -131,14 +135,17 @@ __global__ __launch_bounds__((MrCfg<N2, R1, R2, FR>::NT)) void mrstft_frames_ker
   const int row = tid / TPF, j = tid % TPF;
   c32* zrow = zbuf + row * ZP;
   // ---- forward pass A (both signals)
+  c32 v[R2];
   if (j < R1) {
     const float* x = xs + (row >= FR ? nS : 0) + (row % FR) * hop;
-    c32 v[R2];
 #pragma unroll
     for (int m2 = 0; m2 < R2; ++m2) {
       const int n = 2 * (j + R1 * m2);
       v[m2] = {x[n] * wn[n], x[n + 1] * wn[n + 1]};
     }
+  }
+  __syncthreads();   // every frame has its samples: the complex buffer may overwrite them
+  if (j < R1) {
     Dft<R2>::run(v);
     zrow[j * R2] = v[0];
 #pragma unroll
