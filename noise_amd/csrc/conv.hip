@@ -611,7 +611,8 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   LazySrc A{a_y, a_coef, a_relu6}, Bs{b_y, b_coef, b_relu6};
   if (check_size("noise_dw3x3_bwd", (long)B * d.Ho * d.Wo + (long)B * Hi * Wi, C)) return -1;
   const int PPB = 256 / (C / 4);
-  const size_t smem = (size_t)PPB * 11 * C * sizeof(float);
+  // the walkers keep their table of per-channel constants (BT_ROWS rows) in the reduction buffer
+  const size_t smem = (size_t)(PPB * 11 > BT_ROWS ? PPB * 11 : BT_ROWS) * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
   int grid;

@@ -226,13 +226,79 @@ __device__ __forceinline__ float4 bwd_activation(const BwdPixel& p, size_t off, 
   return av;
 }
 
+// Per-channel constants of a backward walker (9 taps, 6 gradient vectors, scale/shift of both sources, 5 epilogue
+// vectors) would sit in ~96 registers of every thread for the whole walk.  They live in LDS instead: one copy per
+// workgroup, written once, read back with a few ds_read_b128 per step, so that two waves fit a SIMD.  The table shares
+// the reduction buffer, which is not touched before the walk has ended.
+enum { BT_W = 0, BT_G = 9, BT_A = 15, BT_B = 17, BT_E = 19, BT_ROWS = 24 };
+
+__device__ __forceinline__ void bwd_table_fill(float* tab, int C, int c, const LazyGrad& G, const LazySrc& A,
+                                               const LazySrc& Bsrc, const BwdEpilogue& E, const float* __restrict__ w,
+                                               bool flip) {
+  float4 wk[9];
+  load_taps(w, c, flip, wk);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) st4(tab + (BT_W + k) * C + c, wk[k]);
+  const LazyGrad4 g = lazygrad4_init(G, C, c);
+  st4(tab + (BT_G + 0) * C + c, g.s);
+  st4(tab + (BT_G + 1) * C + c, g.k1h);
+  st4(tab + (BT_G + 2) * C + c, g.k1l);
+  st4(tab + (BT_G + 3) * C + c, g.a2);
+  st4(tab + (BT_G + 4) * C + c, g.mh);
+  st4(tab + (BT_G + 5) * C + c, g.ml);
+  const Lazy4 a = lazy4_init(A, C, c), b = lazy4_init(Bsrc, C, c);
+  st4(tab + (BT_A + 0) * C + c, a.scale);
+  st4(tab + (BT_A + 1) * C + c, a.shift);
+  st4(tab + (BT_B + 0) * C + c, b.scale);
+  st4(tab + (BT_B + 1) * C + c, b.shift);
+  const Epi4 e = epi4_init(E, C, c);
+  st4(tab + (BT_E + 0) * C + c, e.scale);
+  st4(tab + (BT_E + 1) * C + c, e.shift);
+  st4(tab + (BT_E + 2) * C + c, e.mean);
+  st4(tab + (BT_E + 3) * C + c, e.mlo);
+  st4(tab + (BT_E + 4) * C + c, e.istd);
+}
+
+// The structs below are used with their scalar members only (pointers, bounds, flags); these return a copy whose
+// vector members come from the table at t = tab + c.
+__device__ __forceinline__ float4 bt_w(const float* t, int C, int k) { return ld4(t + (BT_W + k) * C); }
+__device__ __forceinline__ LazyGrad4 bt_grad(LazyGrad4 m, const float* t, int C) {
+  m.s = ld4(t + (BT_G + 0) * C);
+  m.k1h = ld4(t + (BT_G + 1) * C);
+  m.k1l = ld4(t + (BT_G + 2) * C);
+  m.a2 = ld4(t + (BT_G + 3) * C);
+  m.mh = ld4(t + (BT_G + 4) * C);
+  m.ml = ld4(t + (BT_G + 5) * C);
+  return m;
+}
+__device__ __forceinline__ Lazy4 bt_src(Lazy4 m, const float* t, int C, int row) {
+  m.scale = ld4(t + row * C);
+  m.shift = ld4(t + (row + 1) * C);
+  return m;
+}
+__device__ __forceinline__ Epi4 bt_epi(Epi4 m, const float* t, int C) {
+  m.scale = ld4(t + (BT_E + 0) * C);
+  m.shift = ld4(t + (BT_E + 1) * C);
+  m.mean = ld4(t + (BT_E + 2) * C);
+  m.mlo = ld4(t + (BT_E + 3) * C);
+  m.istd = ld4(t + (BT_E + 4) * C);
+  return m;
+}
+// tab + c behind an offset the compiler cannot see through (it is zero): reads through it stay inside the loop
+// iteration they are written in instead of being hoisted back into registers.
+__device__ __forceinline__ const float* bt_here(const float* tc) {
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  return tc + z;
+}
+
 // RECOMP (stride-2 transposed layers with a BatchNorm behind them): the raw layer output y that the lazy gradient
 // needs (dy = s*(dz - k1) + a2*(y - mean)) is recomputed from the layer input, which is four times smaller and walked
 // anyway, instead of being read back: y(2i-1+r, 2j-1+c) = sum a(i, j) * wk[3r+c] is the adjoint of the gather below.
 // The thread keeps the activated input rows oy and oy+1 at columns ox-1..ox+1; the centre of row oy doubles as the
 // destination pixel's activation.
 template <int S, bool FLIP, bool HAS_B, bool HAS_GO, bool RECOMP = false>
-__global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
+__global__ __launch_bounds__(256, 2) void walk_gather_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
                                                               const float* __restrict__ w, float* __restrict__ g_in,
                                                               float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
   extern __shared__ float red[];
@@ -241,11 +307,14 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
   float4 dwk[11];
 #pragma unroll
   for (int k = 0; k < 11; ++k) dwk[k] = f4(0.f);
+  if (pl == 0) bwd_table_fill(red, C, c, G, A, Bsrc, E, w, FLIP);
+  __syncthreads();
   if (pl < PPB) {
-    BwdPixel px{lazy4_init(A, C, c), lazy4_init(Bsrc, C, c), epi4_init(E, C, c), g_in};
-    const LazyGrad4 gr = lazygrad4_init(G, C, c);
-    float4 wk[9];
-    load_taps(w, c, FLIP, wk);
+    // scalar members only; the per-channel vectors are read from the table where they are used
+    const Lazy4 am = lazy4_init(A, C, c), bm = lazy4_init(Bsrc, C, c);
+    const Epi4 em = epi4_init(E, C, c);
+    const LazyGrad4 gm = lazygrad4_init(G, C, c);
+    const float* const tc = red + c;
     for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
       int bi, r0, r1, ox;
       if (!walk_slot(d, g * PPB + pl, d.Hd, bi, r0, r1, ox)) continue;
@@ -254,6 +323,7 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
       const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
       const int cx0 = v0 ? ix0 : 0, cx1 = v1 ? ix0 + 1 : 0, cx2 = v2 ? ix0 + 2 : 0;
       auto load_row = [&](int iy, float4(&r)[3]) {   // branch-free, see walk_gather_fwd_kernel
+        const LazyGrad4 gr = bt_grad(gm, tc, C);
         const bool vy = iy >= 0 && iy < d.Hs;
         const size_t row = clip + (size_t)(vy ? iy : 0) * d.Ws * C;
         const float4 x0 = lazygrad4_at(gr, row + (size_t)cx0 * C);
@@ -280,42 +350,47 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
         for (int u = 0; u < S; ++u) {
           const int iy = S == 1 ? oy + 1 : 2 * oy + u;
           const size_t row = clip + (size_t)((iy >= 0 && iy < d.Hs) ? iy : 0) * d.Ws * C;
-          rz[u][0] = ld4(gr.dz + row + (size_t)cx0 * C);
-          rz[u][1] = ld4(gr.dz + row + (size_t)cx1 * C);
-          rz[u][2] = ld4(gr.dz + row + (size_t)cx2 * C);
+          rz[u][0] = ld4(gm.dz + row + (size_t)cx0 * C);
+          rz[u][1] = ld4(gm.dz + row + (size_t)cx1 * C);
+          rz[u][2] = ld4(gm.dz + row + (size_t)cx2 * C);
           if (!RECOMP) {
-            ry[u][0] = ld4(gr.y + row + (size_t)cx0 * C);
-            ry[u][1] = ld4(gr.y + row + (size_t)cx1 * C);
-            ry[u][2] = ld4(gr.y + row + (size_t)cx2 * C);
+            ry[u][0] = ld4(gm.y + row + (size_t)cx0 * C);
+            ry[u][1] = ld4(gm.y + row + (size_t)cx1 * C);
+            ry[u][2] = ld4(gm.y + row + (size_t)cx2 * C);
           }
         }
         if (RECOMP) {
           const size_t nrow = ((size_t)bi * d.Hd + (oy + 1 < d.Hd ? oy + 1 : oy)) * d.Wd * C + c;
-          rna[0] = ld4(px.a.y + nrow + nxm);
-          rna[1] = ld4(px.a.y + nrow + nx);
-          rna[2] = ld4(px.a.y + nrow + nxp);
+          rna[0] = ld4(am.y + nrow + nxm);
+          rna[1] = ld4(am.y + nrow + nx);
+          rna[2] = ld4(am.y + nrow + nxp);
           if (HAS_B) {
-            rnb[0] = ld4(px.b.y + nrow + nxm);
-            rnb[1] = ld4(px.b.y + nrow + nx);
-            rnb[2] = ld4(px.b.y + nrow + nxp);
+            rnb[0] = ld4(bm.y + nrow + nxm);
+            rnb[1] = ld4(bm.y + nrow + nx);
+            rnb[2] = ld4(bm.y + nrow + nxp);
           }
         } else {
-          ray = ld4(px.a.y + off);
-          rby = HAS_B ? ld4(px.b.y + off) : f4(0.f);
+          ray = ld4(am.y + off);
+          rby = HAS_B ? ld4(bm.y + off) : f4(0.f);
         }
-        rgo = HAS_GO ? ld4(px.epi.g_other + off) : f4(0.f);
+        rgo = HAS_GO ? ld4(em.g_other + off) : f4(0.f);
       };
       float4 a0[RECOMP ? 3 : 1], a1[RECOMP ? 3 : 1], ymid = f4(0.f);   // activated input rows oy, oy+1; raw centre of row oy
       if (RECOMP) {
+        const Lazy4 pa = bt_src(am, tc, C, BT_A), pb = bt_src(bm, tc, C, BT_B);
+        const LazyGrad4 gr = bt_grad(gm, tc, C);
+        float4 wk[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wk[q] = bt_w(tc, C, q);
         const size_t row = ((size_t)bi * d.Hd + r0) * d.Wd * C + c;
-        const float4 q0 = ld4(px.a.y + row + nxm), q1 = ld4(px.a.y + row + nx), q2 = ld4(px.a.y + row + nxp);
-        a0[0] = lazy4_act(px.a, q0);
-        a0[1] = lazy4_act(px.a, q1);
-        a0[2] = lazy4_act(px.a, q2);
+        const float4 q0 = ld4(am.y + row + nxm), q1 = ld4(am.y + row + nx), q2 = ld4(am.y + row + nxp);
+        a0[0] = lazy4_act(pa, q0);
+        a0[1] = lazy4_act(pa, q1);
+        a0[2] = lazy4_act(pa, q2);
         if (HAS_B) {
-          a0[0] = a0[0] + lazy4_at(px.b, row + nxm);
-          a0[1] = a0[1] + lazy4_at(px.b, row + nx);
-          a0[2] = a0[2] + lazy4_at(px.b, row + nxp);
+          a0[0] = a0[0] + lazy4_at(pb, row + nxm);
+          a0[1] = a0[1] + lazy4_at(pb, row + nx);
+          a0[2] = a0[2] + lazy4_at(pb, row + nxp);
         }
         a0[0] = keep4(vxm, a0[0]);
         a0[2] = keep4(vxp, a0[2]);
@@ -325,13 +400,13 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
         const bool vp = r0 > 0;
         const size_t prow = ((size_t)bi * d.Hd + (vp ? r0 - 1 : r0)) * d.Wd * C + c;
         float4 ap[3];
-        ap[0] = lazy4_at(px.a, prow + nxm);
-        ap[1] = lazy4_at(px.a, prow + nx);
-        ap[2] = lazy4_at(px.a, prow + nxp);
+        ap[0] = lazy4_at(pa, prow + nxm);
+        ap[1] = lazy4_at(pa, prow + nx);
+        ap[2] = lazy4_at(pa, prow + nxp);
         if (HAS_B) {
-          ap[0] = ap[0] + lazy4_at(px.b, prow + nxm);
-          ap[1] = ap[1] + lazy4_at(px.b, prow + nx);
-          ap[2] = ap[2] + lazy4_at(px.b, prow + nxp);
+          ap[0] = ap[0] + lazy4_at(pb, prow + nxm);
+          ap[1] = ap[1] + lazy4_at(pb, prow + nx);
+          ap[2] = ap[2] + lazy4_at(pb, prow + nxp);
         }
         ap[0] = keep4(vxm, ap[0]);
         ap[2] = keep4(vxp, ap[2]);
@@ -347,6 +422,8 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
       issue(r0, ioff);
 #pragma unroll 1
       for (int oy = r0; oy < r1; ++oy, ioff += drow) {
+        const float* t = bt_here(tc);
+        const LazyGrad4 gr = bt_grad(gm, t, C);
         if (S == 1) {
           const bool vy = oy + 1 < d.Hs;
 #pragma unroll
@@ -360,19 +437,19 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
             const bool vn = oy + 1 < d.Hd;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              a1[j] = lazy4_act(px.a, rna[j]);
-              if (HAS_B) a1[j] = a1[j] + lazy4_act(px.b, rnb[j]);
+              a1[j] = lazy4_act(bt_src(am, t, C, BT_A), rna[j]);
+              if (HAS_B) a1[j] = a1[j] + lazy4_act(bt_src(bm, t, C, BT_B), rnb[j]);
             }
             a1[0] = keep4(vn && vxm, a1[0]);
             a1[1] = keep4(vn, a1[1]);
             a1[2] = keep4(vn && vxp, a1[2]);
             float4 y0[3], y1[3];
-            y0[0] = fma4(a0[0], wk[5], a0[1] * wk[3]);
-            y0[1] = a0[1] * wk[4];
-            y0[2] = fma4(a0[2], wk[3], a0[1] * wk[5]);
-            y1[0] = fma4(a1[1], wk[0], fma4(a1[0], wk[2], fma4(a0[1], wk[6], a0[0] * wk[8])));
-            y1[1] = fma4(a1[1], wk[1], a0[1] * wk[7]);
-            y1[2] = fma4(a1[2], wk[0], fma4(a1[1], wk[2], fma4(a0[2], wk[6], a0[1] * wk[8])));
+            y0[0] = fma4(a0[0], bt_w(t, C, 5), a0[1] * bt_w(t, C, 3));
+            y0[1] = a0[1] * bt_w(t, C, 4);
+            y0[2] = fma4(a0[2], bt_w(t, C, 3), a0[1] * bt_w(t, C, 5));
+            y1[0] = fma4(a1[1], bt_w(t, C, 0), fma4(a1[0], bt_w(t, C, 2), fma4(a0[1], bt_w(t, C, 6), a0[0] * bt_w(t, C, 8))));
+            y1[1] = fma4(a1[1], bt_w(t, C, 1), a0[1] * bt_w(t, C, 7));
+            y1[2] = fma4(a1[2], bt_w(t, C, 0), fma4(a1[1], bt_w(t, C, 2), fma4(a0[2], bt_w(t, C, 6), a0[1] * bt_w(t, C, 8))));
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
               t1[j] = lazygrad4_eval(gr, rz[0][j], y0[j]);
@@ -400,28 +477,29 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
 #pragma unroll
           for (int j = 0; j < 3; ++j) a0[j] = a1[j];
         } else {
-          av = lazy4_act(px.a, yraw);
-          if (HAS_B) av = av + lazy4_act(px.b, rby);
+          av = lazy4_act(bt_src(am, t, C, BT_A), yraw);
+          if (HAS_B) av = av + lazy4_act(bt_src(bm, t, C, BT_B), rby);
         }
         const float4 go = rgo;
         issue(oy + 1 < r1 ? oy + 1 : oy, oy + 1 < r1 ? ioff + drow : ioff);   // next step (a harmless repeat at the end)
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic below
-        float4 acc = t0[0] * wk[0];
-        acc = fma4(t0[1], wk[1], acc);
-        acc = fma4(t0[2], wk[2], acc);
-        acc = fma4(t1[0], wk[3], acc);
-        acc = fma4(t1[1], wk[4], acc);
-        acc = fma4(t1[2], wk[5], acc);
-        acc = fma4(t2[0], wk[6], acc);
-        acc = fma4(t2[1], wk[7], acc);
-        acc = fma4(t2[2], wk[8], acc);
+        const float* u = bt_here(tc);   // a second window: the taps are not held across the requests above
+        float4 acc = t0[0] * bt_w(u, C, 0);
+        acc = fma4(t0[1], bt_w(u, C, 1), acc);
+        acc = fma4(t0[2], bt_w(u, C, 2), acc);
+        acc = fma4(t1[0], bt_w(u, C, 3), acc);
+        acc = fma4(t1[1], bt_w(u, C, 4), acc);
+        acc = fma4(t1[2], bt_w(u, C, 5), acc);
+        acc = fma4(t2[0], bt_w(u, C, 6), acc);
+        acc = fma4(t2[1], bt_w(u, C, 7), acc);
+        acc = fma4(t2[2], bt_w(u, C, 8), acc);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           dwk[j] = fma4(t0[j], av, dwk[j]);
           dwk[3 + j] = fma4(t1[j], av, dwk[3 + j]);
           dwk[6 + j] = fma4(t2[j], av, dwk[6 + j]);
         }
-        acc = epi4_core(px.epi, acc + go, yraw, dwk[9], dwk[10]);
+        acc = epi4_core(bt_epi(em, u, C), acc + go, yraw, dwk[9], dwk[10]);
         if (g_in != nullptr) st4(g_in + ioff, acc);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -448,7 +526,7 @@ __global__ __launch_bounds__(256) void walk_gather_bwd_kernel(LazyGrad G, LazySr
 
 // backward of a stride-2 Conv2d: cell geometry over dy
 template <bool HAS_B, bool HAS_GO>
-__global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
+__global__ __launch_bounds__(256, 2) void walk_cell_bwd_kernel(LazyGrad G, LazySrc A, LazySrc Bsrc,
                                                             const float* __restrict__ w, float* __restrict__ g_in,
                                                             float* __restrict__ dw_slab, BwdEpilogue E, WalkDims d) {
   extern __shared__ float red[];
@@ -457,11 +535,14 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
   float4 dwk[11];
 #pragma unroll
   for (int k = 0; k < 11; ++k) dwk[k] = f4(0.f);
+  if (pl == 0) bwd_table_fill(red, C, c, G, A, Bsrc, E, w, false);
+  __syncthreads();
   if (pl < PPB) {
-    BwdPixel px{lazy4_init(A, C, c), lazy4_init(Bsrc, C, c), epi4_init(E, C, c), g_in};
-    const LazyGrad4 gr = lazygrad4_init(G, C, c);
-    float4 wk[9];
-    load_taps(w, c, false, wk);
+    // scalar members only; the per-channel vectors are read from the table where they are used
+    const Lazy4 am = lazy4_init(A, C, c), bm = lazy4_init(Bsrc, C, c);
+    const Epi4 em = epi4_init(E, C, c);
+    const LazyGrad4 gm = lazygrad4_init(G, C, c);
+    const float* const tc = red + c;
     for (int g = blockIdx.x; g < d.ngroups; g += gridDim.x) {
       int bi, m0, m1, mx;
       if (!walk_slot(d, g * PPB + pl, d.Hs, bi, m0, m1, mx)) continue;
@@ -469,6 +550,7 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
       const bool dx1 = 2 * mx + 1 < d.Wd;
       const size_t clip = (size_t)bi * d.Hs * d.Ws * C + c;
       auto load_row = [&](int iy, float4& r0, float4& r1) {   // branch-free, see walk_gather_fwd_kernel
+        const LazyGrad4 gr = bt_grad(gm, tc, C);
         const bool vy = iy < d.Hs;
         const size_t o0 = clip + ((size_t)(vy ? iy : 0) * d.Ws + mx) * C;
         const float4 x0 = lazygrad4_at(gr, o0), x1 = lazygrad4_at(gr, vx1 ? o0 + C : o0);
@@ -486,29 +568,32 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
       auto issue = [&](int m, size_t off) {
         const int iy = m + 1;
         const size_t o0 = clip + ((size_t)(iy < d.Hs ? iy : 0) * d.Ws + mx) * C, o1 = vx1 ? o0 + C : o0;
-        rz0 = ld4(gr.dz + o0);
-        rz1 = ld4(gr.dz + o1);
-        ry0 = ld4(gr.y + o0);
-        ry1 = ld4(gr.y + o1);
+        rz0 = ld4(gm.dz + o0);
+        rz1 = ld4(gm.dz + o1);
+        ry0 = ld4(gm.y + o0);
+        ry1 = ld4(gm.y + o1);
         const bool k10 = 2 * m + 1 < d.Hd;
-        ra[0] = ld4(px.a.y + off);
-        ra[1] = ld4(px.a.y + (dx1 ? off + C : off));
-        ra[2] = ld4(px.a.y + (k10 ? off + drow : off));
-        ra[3] = ld4(px.a.y + ((k10 && dx1) ? off + drow + C : off));
+        ra[0] = ld4(am.y + off);
+        ra[1] = ld4(am.y + (dx1 ? off + C : off));
+        ra[2] = ld4(am.y + (k10 ? off + drow : off));
+        ra[3] = ld4(am.y + ((k10 && dx1) ? off + drow + C : off));
       };
+      const float* t = tc;   // table window of the current step
       auto activate = [&](float4 yraw, size_t off) {
-        float4 av = lazy4_act(px.a, yraw);
-        if (HAS_B) av = av + lazy4_at(px.b, off);
+        float4 av = lazy4_act(bt_src(am, t, C, BT_A), yraw);
+        if (HAS_B) av = av + lazy4_at(bt_src(bm, t, C, BT_B), off);
         return av;
       };
       auto finish = [&](float4 g, float4 yraw, size_t off, bool ok) {   // + second gradient, mask, producer sums
-        if (HAS_GO) g = g + keep4(ok, ld4(px.epi.g_other + off));
-        return epi4_core(px.epi, g, yraw, dwk[9], dwk[10]);
+        if (HAS_GO) g = g + keep4(ok, ld4(em.g_other + off));
+        return epi4_core(bt_epi(em, t, C), g, yraw, dwk[9], dwk[10]);
       };
       issue(m0, ioff);
 #pragma unroll 1
       for (int m = m0; m < m1; ++m, ioff += 2 * drow) {
         const bool vy = m + 1 < d.Hs;
+        t = bt_here(tc);
+        const LazyGrad4 gr = bt_grad(gm, t, C);
         s10 = keep4(vy, lazygrad4_eval(gr, rz0, ry0));
         s11 = keep4(vy && vx1, lazygrad4_eval(gr, rz1, ry1));
         const bool ok01 = dx1, ok10 = 2 * m + 1 < d.Hd, ok11 = ok10 && dx1;
@@ -517,15 +602,16 @@ __global__ __launch_bounds__(256) void walk_cell_bwd_kernel(LazyGrad G, LazySrc 
         const float4 y00 = ra[0], y01 = ra[1], y10 = ra[2], y11 = ra[3];
         issue(m + 1 < m1 ? m + 1 : m, m + 1 < m1 ? ioff + 2 * drow : ioff);
         __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic below
+        t = bt_here(tc);
         const float4 a00 = activate(y00, o00), a01 = keep4(ok01, activate(y01, o01));
         const float4 a10 = keep4(ok10, activate(y10, o10)), a11 = keep4(ok11, activate(y11, o11));
-        float4 g00 = s00 * wk[4];
-        float4 g01 = fma4(s01, wk[3], s00 * wk[5]);
-        float4 g10 = fma4(s10, wk[1], s00 * wk[7]);
-        float4 g11 = s00 * wk[8];
-        g11 = fma4(s01, wk[6], g11);
-        g11 = fma4(s10, wk[2], g11);
-        g11 = fma4(s11, wk[0], g11);
+        float4 g00 = s00 * bt_w(t, C, 4);
+        float4 g01 = fma4(s01, bt_w(t, C, 3), s00 * bt_w(t, C, 5));
+        float4 g10 = fma4(s10, bt_w(t, C, 1), s00 * bt_w(t, C, 7));
+        float4 g11 = s00 * bt_w(t, C, 8);
+        g11 = fma4(s01, bt_w(t, C, 6), g11);
+        g11 = fma4(s10, bt_w(t, C, 2), g11);
+        g11 = fma4(s11, bt_w(t, C, 0), g11);
         dwk[4] = fma4(s00, a00, dwk[4]);
         dwk[5] = fma4(s00, a01, dwk[5]);
         dwk[3] = fma4(s01, a01, dwk[3]);
