@@ -402,6 +402,27 @@ int noise_ofa_last_convT(const float* src_y, const float* src_coef, int src_relu
 int noise_ofa_final(const float* y, const float* coef, int relu6, float* out, int B, int Hy, int Wy, int H, int W,
                     void* stream);
 
+/* ---- shape-generic forward of configurations outside the tuned schedule: the waveform-domain U-Net of
+ * train/configs/mobilenetv2.yaml (train/models.py:1096-1218 under Base, :541-626) runs on the generic convolution
+ * kernels above plus the token-level pieces of the transformer bottleneck below -------------------------------------- */
+/* Base._normalize (models.py:614-622): mx[b] = max|x[b]| + 1e-6, out = x / mx; x, out [B][L] */
+int noise_wave_normalize(const float* x, float* out, float* mx, int B, long L, void* stream);
+/* Base.forward's tail (models.py:578-580, :610, :624-626): out [B][H][W] = (y cropped from the end of [B][Hy][Wy] + bias[0])
+ * * sigmoid(1e4 * vad[b]) * mx[b]; bias, vad and mx may each be null (term skipped) */
+int noise_wave_final(const float* y, const float* bias, const float* vad, const float* mx, float* out, int B, int Hy, int Wy,
+                     int H, int W, void* stream);
+/* out[t][:D] = LayerNorm(act(y[t] + bias) + res[t]) * gamma + beta (models.py:88-92, :109-118, :214); bias / res may be
+ * null, relu != 0 applies max(., 0) before the residual, gamma == beta == null skips the normalisation; D <= 1024 */
+int noise_tok_epilogue(const float* y, int ldy, const float* bias, int relu, const float* res, int ldr, const float* gamma,
+                       const float* beta, float eps, float* out, int ldo, long M, int D, void* stream);
+/* ScaledDotProductAttention (models.py:14-36): q, k, v [B*n][ld] with head h in columns [h*dk, (h+1)*dk), dk <= 64, any n;
+ * out [B*n][ldo] = softmax(q k^T / temperature) (* keep * keep_scale) v; keep [B][H][n][n] bytes (0 = dropped) or null */
+int noise_tok_attention(const float* q, const float* k, const float* v, int ld, const unsigned char* keep, float keep_scale,
+                        float* out, int ldo, int B, int n, int H, int dk, float temperature, void* stream);
+/* vad[b] = x[b, token 0, :D] . w + bias[0] (models.py:601); x [B][tokens_per_clip][ld] */
+int noise_tok_vad(const float* x, int ld, long tokens_per_clip, const float* w, const float* bias, float* vad, int B, int D,
+                  void* stream);
+
 /* ---- micro-benchmarks of the two rooflines (no counterpart in the reference; not on the product path) ----------- */
 /* dst = src (n floats, n % 4 == 0): 8 * n bytes of HBM traffic */
 int noise_bench_copy(const float* src, float* dst, long n, void* stream);

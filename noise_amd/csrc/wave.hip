@@ -1,0 +1,225 @@
+// Shape-generic kernels for configurations outside the tuned schedule: the token-level pieces of the transformer
+// bottleneck (train/models.py:14-225) for any model width / head size / sequence length, and the waveform-domain wrapper
+// of Base.forward (train/models.py:576-581, :614-626).  Together with the generic convolution kernels of ofa.hip they
+// run the forward pass of the waveform-domain U-Net (train/configs/mobilenetv2.yaml).
+#include "common.h"
+
+namespace {
+
+// ---- per-clip normaliser (models.py:614-622): mx[b] = max|x[b]| + 1e-6, out = x / mx -----------------------------------
+__global__ __launch_bounds__(256) void wave_normalize_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             float* __restrict__ mx, long L) {
+  __shared__ float red[4];
+  const float* xb = x + (size_t)blockIdx.x * L;
+  float m = 0.f;
+  for (long i = threadIdx.x; i < L; i += 256) m = fmaxf(m, fabsf(xb[i]));
+  m = wave_reduce_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) + 1e-6f;
+  if (threadIdx.x == 0) mx[blockIdx.x] = m;
+  float* ob = out + (size_t)blockIdx.x * L;
+  for (long i = threadIdx.x; i < L; i += 256) ob[i] = xb[i] / m;
+}
+
+// ---- out = (y[crop from the end] + bias) * sigmoid(1e4 * vad) * mx   (models.py:578-580, :610, :624-626) ---------------
+__global__ __launch_bounds__(256) void wave_final_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                         const float* __restrict__ vad, const float* __restrict__ mx,
+                                                         float* __restrict__ out, int B, int Hy, int Wy, int H, int W) {
+  const long n = (long)B * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const long t = i / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float v = y[((size_t)b * Hy + (Hy - H + h)) * Wy + (Wy - W + w)] + (bias ? bias[0] : 0.f);
+    if (vad) v *= 1.f / (1.f + expf(-1e4f * vad[b]));
+    if (mx) v *= mx[b];
+    out[i] = v;
+  }
+}
+
+// ---- token epilogue: out[t] = LayerNorm(act(y[t] + bias) + res[t]) (models.py:88-92, :109-118); one wave per token ------
+constexpr int TOK_PER = 16;   // features per lane: D <= 1024
+
+__global__ __launch_bounds__(256) void tok_epilogue_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ bias,
+                                                           int relu, const float* __restrict__ res, int ldr,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float* __restrict__ out, int ldo, long M, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long t = (long)blockIdx.x * 4 + wave; t < M; t += (long)gridDim.x * 4) {
+    float v[TOK_PER];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < TOK_PER; ++j) {
+      const int i = lane + 64 * j;
+      float x = 0.f;
+      if (i < D) {
+        x = y[(size_t)t * ldy + i];
+        if (bias) x += bias[i];
+        if (relu) x = fmaxf(x, 0.f);
+        if (res) x += res[(size_t)t * ldr + i];
+      }
+      v[j] = x;
+      s += x;
+    }
+    if (gamma != nullptr) {
+      const float mean = wave_reduce_sum(s) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < TOK_PER; ++j) {
+        const float dlt = v[j] - mean;
+        q += (lane + 64 * j < D) ? dlt * dlt : 0.f;
+      }
+      const float rstd = 1.f / sqrtf(wave_reduce_sum(q) / (float)D + eps);
+#pragma unroll
+      for (int j = 0; j < TOK_PER; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) out[(size_t)t * ldo + i] = (v[j] - mean) * rstd * gamma[i] + beta[i];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TOK_PER; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) out[(size_t)t * ldo + i] = v[j];
+      }
+    }
+  }
+}
+
+// ---- scaled dot-product attention (models.py:14-36) for one (clip, head, block of 256 queries) ----------------------------
+// A thread owns a query; the keys and values of the head pass through LDS in blocks of 128, the softmax runs online (a
+// running maximum, the sums rescaled when it moves).  An optional keep mask (0/1 per query-key pair) is the attention
+// dropout: masked weights drop out of the numerator only, the kept ones are scaled by keep_scale = 1 / (1 - p).
+constexpr int ATT_KB = 128;
+
+template <int DKP>
+__global__ __launch_bounds__(256) void tok_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, int ld,
+                                                            const unsigned char* __restrict__ keep, float keep_scale,
+                                                            float* __restrict__ out, int ldo, int n, int H, int dk,
+                                                            float inv_temp) {
+  __shared__ float Ks[ATT_KB * DKP];
+  __shared__ float Vs[ATT_KB * DKP];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  const size_t row0 = (size_t)b * n;
+  float qr[DKP], acc[DKP];
+#pragma unroll
+  for (int d = 0; d < DKP; ++d) {
+    qr[d] = (live && d < dk) ? q[(row0 + i) * ld + h * dk + d] * inv_temp : 0.f;
+    acc[d] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  const unsigned char* kp = keep ? keep + (((size_t)b * H + h) * n + (live ? i : 0)) * n : nullptr;
+  for (int j0 = 0; j0 < n; j0 += ATT_KB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < ATT_KB * DKP; e += 256) {
+      const int j = e / DKP, d = e - j * DKP;
+      const bool in = j0 + j < n && d < dk;
+      Ks[e] = in ? k[(row0 + j0 + j) * ld + h * dk + d] : 0.f;
+      Vs[e] = in ? v[(row0 + j0 + j) * ld + h * dk + d] : 0.f;
+    }
+    __syncthreads();
+    const int jn = n - j0 < ATT_KB ? n - j0 : ATT_KB;
+    for (int j = 0; j < jn; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
+      if (s > m) {
+        const float c = expf(m - s);   // 0 on the first key (m = -inf)
+        l *= c;
+#pragma unroll
+        for (int d = 0; d < DKP; ++d) acc[d] *= c;
+        m = s;
+      }
+      const float p = expf(s - m);
+      l += p;
+      const float pk = kp ? (kp[j0 + j] ? p * keep_scale : 0.f) : p;
+#pragma unroll
+      for (int d = 0; d < DKP; ++d) acc[d] = fmaf(pk, Vs[j * DKP + d], acc[d]);
+    }
+  }
+  if (live) {
+    const float r = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < DKP; ++d)
+      if (d < dk) out[(row0 + i) * ldo + h * dk + d] = acc[d] * r;
+  }
+}
+
+// ---- voice-activity logit of a clip from its first token (models.py:601): one wave per clip --------------------------------
+__global__ __launch_bounds__(64) void tok_vad_kernel(const float* __restrict__ x, int ld, long tokens_per_clip,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ vad, int D) {
+  const float* row = x + (size_t)blockIdx.x * tokens_per_clip * ld;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 64) s = fmaf(row[i], w[i], s);
+  s = wave_reduce_sum(s);
+  if (threadIdx.x == 0) vad[blockIdx.x] = s + bias[0];
+}
+
+}  // namespace
+
+NOISE_EXPORT int noise_wave_normalize(const float* x, float* out, float* mx, int B, long L, void* stream) {
+  NOISE_REQUIRE(x && out && mx, "noise_wave_normalize: null pointer");
+  NOISE_REQUIRE(B > 0 && L > 0, "noise_wave_normalize: empty input");
+  hipLaunchKernelGGL(wave_normalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, mx, L);
+  NOISE_CHECK_LAUNCH("noise_wave_normalize");
+  return 0;
+}
+
+NOISE_EXPORT int noise_wave_final(const float* y, const float* bias, const float* vad, const float* mx, float* out, int B,
+                                  int Hy, int Wy, int H, int W, void* stream) {
+  NOISE_REQUIRE(y && out, "noise_wave_final: null pointer");
+  NOISE_REQUIRE(B > 0 && H > 0 && W > 0 && Hy >= H && Wy >= W, "noise_wave_final: the network output (%d x %d) is smaller than "
+                "the input (%d x %d)", Hy, Wy, H, W);
+  hipLaunchKernelGGL(wave_final_kernel, dim3(noise_grid((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, vad,
+                     mx, out, B, Hy, Wy, H, W);
+  NOISE_CHECK_LAUNCH("noise_wave_final");
+  return 0;
+}
+
+NOISE_EXPORT int noise_tok_epilogue(const float* y, int ldy, const float* bias, int relu, const float* res, int ldr,
+                                    const float* gamma, const float* beta, float eps, float* out, int ldo, long M, int D,
+                                    void* stream) {
+  NOISE_REQUIRE(y && out, "noise_tok_epilogue: null pointer");
+  NOISE_REQUIRE(M > 0 && D > 0 && D <= 64 * TOK_PER, "noise_tok_epilogue: 1 <= D <= %d (got %d)", 64 * TOK_PER, D);
+  NOISE_REQUIRE(ldy >= D && ldo >= D && (!res || ldr >= D), "noise_tok_epilogue: row strides shorter than D");
+  NOISE_REQUIRE((gamma == nullptr) == (beta == nullptr), "noise_tok_epilogue: LayerNorm needs both weight and bias");
+  hipLaunchKernelGGL(tok_epilogue_kernel, dim3(noise_grid(M, 4, 4096)), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, relu,
+                     res, ldr, gamma, beta, eps, out, ldo, M, D);
+  NOISE_CHECK_LAUNCH("noise_tok_epilogue");
+  return 0;
+}
+
+NOISE_EXPORT int noise_tok_attention(const float* q, const float* k, const float* v, int ld, const unsigned char* keep,
+                                     float keep_scale, float* out, int ldo, int B, int n, int H, int dk, float temperature,
+                                     void* stream) {
+  NOISE_REQUIRE(q && k && v && out, "noise_tok_attention: null pointer");
+  NOISE_REQUIRE(B > 0 && n > 0 && H > 0 && dk > 0 && dk <= 64, "noise_tok_attention: head size must be in 1..64 (got %d)", dk);
+  NOISE_REQUIRE(B <= 65535 && H <= 65535, "noise_tok_attention: more than 65535 clips or heads in one call");
+  NOISE_REQUIRE(ld >= H * dk && ldo >= H * dk && temperature > 0.f, "noise_tok_attention: bad strides or temperature");
+  const dim3 grid(noise_cdiv(n, 256), H, B);
+  hipStream_t st = (hipStream_t)stream;
+  const float it = 1.f / temperature;
+#define ATT_CASE(P)                                                                                                     \
+  hipLaunchKernelGGL(tok_attention_kernel<P>, grid, dim3(256), 0, st, q, k, v, ld, keep, keep_scale, out, ldo, n, H, dk, it)
+  if (dk <= 8) ATT_CASE(8);
+  else if (dk <= 16) ATT_CASE(16);
+  else if (dk <= 24) ATT_CASE(24);
+  else if (dk <= 32) ATT_CASE(32);
+  else ATT_CASE(64);
+#undef ATT_CASE
+  NOISE_CHECK_LAUNCH("noise_tok_attention");
+  return 0;
+}
+
+NOISE_EXPORT int noise_tok_vad(const float* x, int ld, long tokens_per_clip, const float* w, const float* bias, float* vad, int B,
+                               int D, void* stream) {
+  NOISE_REQUIRE(x && w && bias && vad, "noise_tok_vad: null pointer");
+  NOISE_REQUIRE(B > 0 && D > 0 && ld >= D && tokens_per_clip > 0, "noise_tok_vad: bad shape");
+  hipLaunchKernelGGL(tok_vad_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, ld, tokens_per_clip, w, bias, vad, D);
+  NOISE_CHECK_LAUNCH("noise_tok_vad");
+  return 0;
+}

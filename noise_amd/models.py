@@ -105,8 +105,6 @@ class InvertedResidual(nn.Module):
         self.stride = stride
         hidden = int(round(inp * expand_ratio))
         self.use_res_connect = stride[-1] == 1 and inp == oup
-        if self.use_res_connect:
-            raise NotImplementedError("residual inverted-residual blocks (stride 1, inp == oup) are not scheduled")
         layers = []
         if expand_ratio != 1:
             layers.append(_conv_norm_act(inp, hidden, 1, (1, 1), 1, True, True))
@@ -148,8 +146,6 @@ class TransformerEncoder(nn.Module):
 
     def __init__(self, d_model, d_inner, n_layers, n_head, d_k, d_v):
         super().__init__()
-        if n_layers != 1:
-            raise NotImplementedError("the kernel schedule covers num_layers == 1 (the reference's configuration)")
         self.layer_stack = nn.ModuleList([_EncoderLayer(d_model, d_inner, n_head, d_k, d_v) for _ in range(n_layers)])
         self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
         self.d_model = d_model
@@ -185,8 +181,18 @@ class VADMobileNetV2(_LightningModule):
         self._first_row = cfg[0]
         self.layer_config = cfg[1:]
         _, c0, _, k, s = self._first_row
-        if list(k) != [3, 3] or any(list(r[3]) != [3, 3] for r in self.layer_config):
-            raise NotImplementedError("only 3x3 kernels are scheduled")
+        kernels = [list(k)] + [list(r[3]) for r in self.layer_config]
+        if any(kk not in ([3, 3], [1, 3]) for kk in kernels):
+            raise NotImplementedError("only 3x3 and 1x3 kernels are scheduled")
+        # The tuned per-layer engine (training, graphs, the block-fused bf16 path) serves the spectral configuration
+        # family: 3x3 kernels, one block per row without residual connection, one encoder layer.  Anything else in the
+        # reference's constructor range (the waveform-domain train/configs/mobilenetv2.yaml: 1x3 kernels, repeated
+        # residual blocks, two encoder layers, d_model 128) is served by the shape-generic forward of `generic.py`.
+        why = []
+        if any(kk != [3, 3] for kk in kernels):
+            why.append("non-3x3 kernels")
+        if num_layers != 1:
+            why.append(f"num_layers = {num_layers}")
         c0 = _make_divisible(c0 * width_mult, round_nearest)
         self._enc_plan = [dict(kind="first", cin=1, cout=c0, stride=tuple(s))]
         self._dec_plan = [dict(kind="last", cin=c0, cout=1, stride=tuple(s))]
@@ -202,7 +208,12 @@ class VADMobileNetV2(_LightningModule):
                 self._enc_plan.append(dict(kind="ir", cin=cin, cout=cout, t=t, stride=stride, hidden=int(round(cin * t))))
                 self._dec_plan.insert(0, dict(kind="irT", cin=cout, cout=cin, t=t, stride=stride,
                                               hidden=int(round(cout * t))))
+                if stride[-1] == 1 and cin == cout:
+                    why.append("residual inverted-residual blocks")
                 cin = cout
+        self.untuned = ", ".join(dict.fromkeys(why)) or None
+        self.attn_dropout = 0.1        # ScaledDotProductAttention's own default (train/models.py:22), train mode only
+        self.attn_keep_masks = None    # optional explicit keep masks, one (B, heads, n, n) uint8 tensor per encoder layer
         hidden = self.layer_config[-1][1]
         self.n_head = nhead
         self.d_k = hidden // nhead
@@ -254,6 +265,9 @@ class VADMobileNetV2(_LightningModule):
     def plan(self, B, H, W, device, fused=False):
         """Buffers + schedule for one geometry: the per-layer fp32 engine, or (fused=True) the block-fused bf16
         inference kernels."""
+        if self.untuned:
+            raise NotImplementedError(f"the tuned kernel schedule does not cover this configuration ({self.untuned}); "
+                                      "only the shape-generic forward (`forward` / `_forward`) serves it")
         if not self.searching and not self.found:
             self._search_padding(H, W)
         key = (B, H, W, self.H_padding, self.W_padding, str(device), bool(fused))
@@ -276,6 +290,9 @@ class VADMobileNetV2(_LightningModule):
         """x (B,1,H,W), already normalised -> filters (B,1,H,W), vad (B,1)   (train/models.py:583-612).
         Inference-only entry point kept for interface parity; training goes through VADSpectralV2."""
         _lib.require_cuda(x)
+        if self.untuned:
+            from .generic import GenericForward
+            return GenericForward(self).forward(x)
         B, _, H, W = x.shape
         p = self.plan(B, H, W, x.device)
         xin = x.reshape(B, H, W).contiguous().float()
@@ -287,6 +304,49 @@ class VADMobileNetV2(_LightningModule):
         ops.last_convT_fwd(last.src_a, last.src_b, last.conv.weight, last.conv.bias, None, None, None, filt, B, last.Hi,
                            last.Wi, last.Cin, last.stride, H, W)
         return filt.view(B, 1, H, W), p.vad.view(B, 1).clone()
+
+    @torch.no_grad()
+    def forward(self, waveforms):
+        """Base.forward (train/models.py:576-581): normalise by the per-clip maximum, run the U-Net, gate by
+        sigmoid(1e4 * vad), undo the normalisation.  (B,1,H,W) -> (B,1,H,W)."""
+        _lib.require_cuda(waveforms)
+        from .generic import normalize, finish
+        B, _, H, W = waveforms.shape
+        xn, mx = normalize(waveforms)
+        filt, vad = self._forward(xn)
+        return finish(filt.reshape(B, filt.shape[-2], filt.shape[-1]), None, vad, mx, H, W)
+
+    SEGMENT = 8000  # `_shared_step` reshapes every batch to 0.5 s segments (train/models.py:643-644)
+
+    @torch.no_grad()
+    def _shared_step(self, batch, batch_idx, stage):
+        """Base._shared_step (train/models.py:641-679) as an evaluation: U-Net forward on 8000-sample segments, then
+        smooth-L1 + lambda * multi-resolution STFT loss + VAD cross-entropy (`noise_amd.losses`), logged under the
+        reference's four names.  The returned loss carries no graph: this path has no backward kernels."""
+        from .generic import normalize, finish
+        from .losses import waveform_loss
+        noisy, clean, _ = batch
+        _lib.require_cuda(noisy, clean)
+        noisy = noisy.reshape(-1, 1, 1, self.SEGMENT)
+        clean = clean.reshape(-1, 1, 1, self.SEGMENT).contiguous().float()
+        B = noisy.shape[0]
+        xn, mx = normalize(noisy)
+        filt, vad = self._forward(xn)
+        enhanced = finish(filt.reshape(B, 1, self.SEGMENT), None, None, mx, 1, self.SEGMENT)     # _denormalize, no gate
+        hp = self.hparams
+        loss, l1, mr, vl = waveform_loss(enhanced, clean, vad, hp.mr_stft_lambda, tuple(hp.fft_sizes), tuple(hp.hop_lengths),
+                                         tuple(hp.win_lengths))
+        self.log_dict({f"{stage}_loss": loss, f"{stage}_waveform_loss": l1, f"{stage}_spectral_loss": mr,
+                       f"{stage}_vad_loss": vl}, on_step=False, on_epoch=True, prog_bar=True, logger=True, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        return self._shared_step(batch, batch_idx, "val")
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("the waveform-domain training step (train/models.py:681-682) has no backward kernels: "
+                                  "`validation_step` evaluates the same loss, `noise_amd.losses` differentiates it with "
+                                  "respect to the enhanced waveform, the U-Net's own backward pass is not built")
 
 
 # ----------------------------------------------------------------------------- autograd bridge
@@ -325,6 +385,9 @@ class VADSpectralV2(_LightningModule):
         self.stft = STFT(max_frames=max_frames, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window)
         self.model = VADMobileNetV2(nhead=nhead, num_layers=num_layers, dropout=dropout, layer_config=layer_config,
                                     pad_value=pad_value)
+        if self.model.untuned:
+            raise NotImplementedError(f"the spectral training engine does not cover this configuration "
+                                      f"({self.model.untuned})")
         self._flat_params = None
         self._flat_grads = None
         self._work_grads = None

@@ -120,11 +120,22 @@ def test_flat_parameters_are_views():
 
 
 def test_unsupported_configurations_say_so():
-    from noise_amd import VADMobileNetV2
+    from noise_amd import VADMobileNetV2, VADSpectralV2
+    # two encoder layers / a residual block: the containers build (the shape-generic forward serves them), the tuned
+    # engine and the spectral training model say what they do not cover
+    for layers, lc in [(2, [list(r) for r in LAYER_CONFIG]), (1, [[1, 32, 1, [3, 3], [2, 2]], [1, 32, 1, [3, 3], [1, 1]]])]:
+        m = VADMobileNetV2(6, layers, 0.0, layer_config=lc)
+        assert m.untuned
+        with pytest.raises(NotImplementedError, match="tuned kernel schedule"):
+            m.plan(1, 161, 51, "cpu")
+        with pytest.raises(NotImplementedError, match="spectral training engine"):
+            VADSpectralV2(n_fft=320, hop_length=160, win_length=320, window="hann", nhead=6, num_layers=layers, dropout=0.0,
+                          layer_config=lc, pad_value=-1, max_frames=400)
+    assert VADMobileNetV2(6, 1, 0.0, layer_config=[list(r) for r in LAYER_CONFIG]).untuned is None
     with pytest.raises(NotImplementedError):
-        VADMobileNetV2(6, 2, 0.0, layer_config=[list(r) for r in LAYER_CONFIG])
+        VADMobileNetV2(6, 1, 0.0, layer_config=[[1, 32, 1, [5, 5], [2, 2]], [1, 16, 1, [3, 3], [1, 1]]])
     with pytest.raises(NotImplementedError):
-        VADMobileNetV2(6, 1, 0.0, layer_config=[[1, 32, 1, [3, 3], [2, 2]], [1, 32, 1, [3, 3], [1, 1]]])
+        VADMobileNetV2(6, 1, 0.1, layer_config=[list(r) for r in LAYER_CONFIG])
     with pytest.raises(ValueError):
         VADMobileNetV2(6, 1, 0.0, layer_config=[])
 

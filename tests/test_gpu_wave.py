@@ -1,0 +1,227 @@
+"""The shape-generic forward (noise_amd/generic.py, csrc/wave.hip + csrc/ofa.hip) of the waveform-domain U-Net through the
+C-ABI: against fixture G9 (written by the reference, tests/golden/make_golden_wave.py), against the CPU oracle on other
+inputs, and the token kernels one by one against torch."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_wave as MG  # noqa: E402  (configurations, perturb(); main() is never called here)
+
+pytestmark = pytest.mark.gpu
+
+G9 = np.load(os.path.join(HERE, "golden", "g9_wave.npz"))
+DEV = "cuda:0"
+
+
+def build(name):
+    from noise_amd.models import VADMobileNetV2
+    cfg, seed, _, _ = MG.CASES[name]
+    torch.manual_seed(seed)
+    m = VADMobileNetV2(**MG.kwargs(cfg))
+    MG.perturb(m, seed)
+    with torch.no_grad():
+        m.vad.bias.copy_(torch.from_numpy(G9[f"{name}_vad_bias"]))
+    return m
+
+
+def keep_masks(name, m):
+    out = []
+    for i in range(len(m.bottleneck_attention.layer_stack)):
+        shape = tuple(int(v) for v in G9[f"{name}_keep{i}_shape"])
+        bits = np.unpackbits(G9[f"{name}_keep{i}"])[:int(np.prod(shape))]
+        out.append(torch.from_numpy(bits.reshape(shape).astype(np.uint8)))
+    return out
+
+
+def close(got, want, atol, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    err = np.abs(got - want).max()
+    assert got.shape == want.shape and err <= atol, f"{what}: max |diff| {err:.3e} > {atol:.1e} (scale {np.abs(want).max():.3e})"
+
+
+@pytest.mark.parametrize("name", list(MG.CASES))
+def test_eval_forward_vs_reference_fixture(name):
+    from noise_amd.generic import normalize
+    m = build(name).to(DEV).eval()
+    x1, x2 = torch.from_numpy(G9[f"{name}_x1"]).to(DEV), torch.from_numpy(G9[f"{name}_x2"]).to(DEV)
+    filt, vad = m._forward(normalize(x1)[0])
+    assert (m.H_padding, m.W_padding) == tuple(G9[f"{name}_padding"])
+    close(filt, G9[f"{name}_eval_filters"], 1e-4, "filters")
+    close(vad, G9[f"{name}_eval_vad"], 5e-6, "vad")
+    # the gate sigmoid(1e4 * vad) magnifies the logit's rounding 2500-fold
+    close(m(x1), G9[f"{name}_eval_y1"], 5e-3, "forward")
+    close(m(x2), G9[f"{name}_eval_y2"], 5e-3, "forward, second length (cropped skips)")
+
+
+@pytest.mark.parametrize("name", list(MG.CASES))
+def test_train_forward_vs_reference_fixture(name):
+    from noise_amd.generic import normalize
+    m = build(name).to(DEV).eval()
+    x1 = torch.from_numpy(G9[f"{name}_x1"]).to(DEV)
+    m._forward(normalize(x1)[0])                  # padding search in eval mode, like the generator
+    m.train()
+    m.attn_keep_masks = keep_masks(name, m)
+    filt, vad = m._forward(normalize(x1)[0])
+    # Batch statistics over 2-4 clips condition the deep layers poorly: the reference's own fp32 result is 2.8e-4
+    # (filters) / 5.4e-5 (vad) away from a float64 evaluation on the widest case, 1.1e-4 / 1.2e-6 on the narrow one.
+    close(filt, G9[f"{name}_train_filters"], 1e-3, "filters")
+    close(vad, G9[f"{name}_train_vad"], 2e-4, "vad")
+    bufs = dict(m.named_buffers())
+    for key in G9.files:
+        if key.startswith(f"{name}_buf/"):
+            np.testing.assert_allclose(bufs[key.split("/", 1)[1]].cpu().numpy(), G9[key], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["narrow", "square"])
+def test_search_in_train_mode_moves_the_statistics(name):
+    from noise_amd.generic import normalize
+    m = build(name).to(DEV).train()
+    m.attn_dropout = 0.0
+    x1 = torch.from_numpy(G9[f"{name}_x1"]).to(DEV)
+    filt, _ = m._forward(normalize(x1)[0])
+    assert (m.H_padding, m.W_padding) == tuple(G9[f"{name}_padding"])
+    close(filt, G9[f"{name}_fresh_train_filters"], 1e-3, "filters")
+    bufs = dict(m.named_buffers())
+    for key in G9.files:
+        if key.startswith(f"{name}_fresh/"):
+            np.testing.assert_allclose(bufs[key.split("/", 1)[1]].cpu().numpy(), G9[key], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["yaml", "narrow"])
+def test_validation_step_vs_reference_fixture(name):
+    """Base._shared_step through validation_step (forward on 8000-sample segments + the three losses), as logged."""
+    from noise_amd.generic import normalize
+    m = build(name).to(DEV).eval()
+    x1, clean = torch.from_numpy(G9[f"{name}_x1"]).to(DEV), torch.from_numpy(G9[f"{name}_val_clean"]).to(DEV)
+    m._forward(normalize(x1)[0])                  # the generator's first call: padding found on x1's shape
+    loss = m.validation_step((x1, clean, None), 0)
+    want = G9[f"{name}_val_losses"]
+    got = [float(loss)] + [float(m.logged_metrics[f"val_{k}"]) for k in ("loss", "waveform_loss", "spectral_loss", "vad_loss")]
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    assert not loss.requires_grad
+
+
+def test_ten_second_clip_vs_oracle():
+    """5000 bottleneck tokens per clip: the attention walks its keys in blocks."""
+    from noise_amd.generic import normalize
+    from oracle import wave_unet as owu
+    m = build("yaml").eval()
+    x = MG.wave(77, (2, 1, 1, 160000))
+    want, wvad = owu.forward(m, owu.normalize(x)[0], False)
+    pad = (m.H_padding, m.W_padding)
+    g = build("yaml").to(DEV).eval()
+    got, gvad = g._forward(normalize(x.to(DEV))[0])
+    assert (g.H_padding, g.W_padding) == pad
+    close(got, want.numpy(), 2e-4, "filters")
+    close(gvad, wvad.numpy(), 1e-5, "vad")
+
+
+def test_reference_default_layer_config_runs():
+    """`VADMobileNetV2()` with the constructor's own default rows (models.py:1126-1136: 3x3 kernels, up to four repeated
+    blocks per row, d_model 320) against the oracle."""
+    from noise_amd.generic import normalize
+    from noise_amd.models import VADMobileNetV2
+    from oracle import wave_unet as owu
+    torch.manual_seed(5)
+    m = VADMobileNetV2(nhead=8, num_layers=1, dropout=0.0)
+    MG.perturb(m, 5)
+    x = torch.randn(2, 1, 70, 90, generator=torch.Generator().manual_seed(6))
+    want, wvad = owu.forward(m.eval(), owu.normalize(x)[0], False)
+    pad = (m.H_padding, m.W_padding)
+    m.H_padding = m.W_padding = 0
+    m.searching = m.found = False
+    g = m.to(DEV)
+    got, gvad = g._forward(normalize(x.to(DEV))[0])
+    assert (g.H_padding, g.W_padding) == pad
+    close(got, want.numpy(), 3e-4, "filters")
+    close(gvad, wvad.numpy(), 2e-5, "vad")
+
+
+def test_refusals():
+    from noise_amd.models import VADMobileNetV2
+    m = build("narrow").to(DEV).eval()
+    with pytest.raises(NotImplementedError):          # one-row kernels on an image
+        m._forward(torch.randn(1, 1, 5, 400, device=DEV))
+    with pytest.raises(NotImplementedError):          # no backward kernels
+        m.training_step((None, None, None), 0)
+    with pytest.raises(RuntimeError):                 # CPU tensors are refused: there is no CPU stand-in
+        build("narrow")(torch.randn(1, 1, 1, 400))
+    lc = MG.kwargs(MG.NARROW)["layer_config"]
+    lc[2][4] = [2, 1]
+    with pytest.raises(NotImplementedError):          # a one-row kernel with a row stride
+        VADMobileNetV2(4, 2, 0.0, layer_config=lc).to(DEV).eval()(torch.randn(1, 1, 1, 400, device=DEV))
+
+
+# ---------------------------------------------------------------------------------------------- kernels, one by one
+def _call(name, *args):
+    from noise_amd import _lib, generic  # noqa: F401  (generic registers the entry points)
+    _lib.call(name, *args, _lib.stream())
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("B,n,H,dk,p", [(2, 250, 6, 21, 0.0), (1, 700, 4, 8, 0.1), (3, 37, 3, 32, 0.25), (1, 129, 1, 1, 0.0),
+                                         (2, 300, 2, 40, 0.1)])
+def test_tok_attention(B, n, H, dk, p):
+    g = torch.Generator().manual_seed(n)
+    ld = 3 * H * dk + 5
+    qkv = torch.randn(B * n, ld, generator=g).to(DEV)
+    keep = (torch.rand(B, H, n, n, generator=g) >= p).to(torch.uint8).to(DEV) if p > 0 else None
+    out = torch.zeros(B * n, H * dk + 3, device=DEV)
+    base = qkv.data_ptr()
+    _call("noise_tok_attention", ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * H * dk), ctypes.c_void_p(base + 8 * H * dk),
+          ld, P(keep), 1.0 / (1.0 - p), P(out), H * dk + 3, B, n, H, dk, float(dk) ** 0.5)
+    x = qkv.double().view(B, n, ld)
+    q, k, v = [x[..., i * H * dk:(i + 1) * H * dk].view(B, n, H, dk).transpose(1, 2) for i in range(3)]
+    a = torch.softmax(q / dk ** 0.5 @ k.transpose(2, 3), -1)
+    if keep is not None:
+        a = a * keep.double() / (1 - p)
+    want = (a @ v).transpose(1, 2).reshape(B * n, H * dk)
+    assert (out[:, :H * dk].double() - want).abs().max() < 2e-5
+    assert out[:, H * dk:].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,D,relu,res,ln", [(1000, 128, False, True, True), (77, 32, True, False, False), (5, 321, False, True, True),
+                                             (300, 1024, True, True, True)])
+def test_tok_epilogue(M, D, relu, res, ln):
+    g = torch.Generator().manual_seed(M + D)
+    y = torch.randn(M, D + 4, generator=g).to(DEV)
+    bias = torch.randn(D, generator=g).to(DEV)
+    r = torch.randn(M, D, generator=g).to(DEV) if res else None
+    gamma, beta = (torch.randn(D, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)) if ln else (None, None)
+    out = torch.empty(M, D, device=DEV)
+    _call("noise_tok_epilogue", P(y), D + 4, P(bias), int(relu), P(r), D, P(gamma), P(beta), 1e-6, P(out), D, M, D)
+    v = y[:, :D].double() + bias.double()
+    if relu:
+        v = v.clamp_min(0)
+    if res:
+        v = v + r.double()
+    if ln:
+        v = torch.nn.functional.layer_norm(v, (D,), gamma.double(), beta.double(), 1e-6)
+    assert (out.double() - v).abs().max() < 2e-5
+
+
+def test_wave_normalize_and_final():
+    from noise_amd.generic import finish, normalize
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 1, 1, 7001, generator=g).to(DEV) * 0.3
+    x[2] = 0
+    xn, mx = normalize(x)
+    want_mx = x.abs().amax(dim=(1, 2, 3)) + 1e-6
+    assert torch.equal(mx, want_mx) and torch.equal(xn, x / want_mx.view(-1, 1, 1, 1))
+    y = torch.randn(5, 3, 7100, generator=g).to(DEV)
+    bias = torch.tensor([0.25], device=DEV)
+    vad = torch.tensor([[1e-5], [-1e-5], [3.0], [-3.0], [0.0]], device=DEV)
+    out = finish(y, bias, vad, mx, 2, 7001)
+    want = (y[:, None, -2:, -7001:] + 0.25) * torch.sigmoid(1e4 * vad.view(-1, 1, 1, 1)) * mx.view(-1, 1, 1, 1)
+    assert out.shape == want.shape and (out - want).abs().max() < 1e-6
+    small = finish(y[:, :1, :50].contiguous(), None, None, None, 2, 7001)       # smaller than asked: returned whole
+    assert small.shape == (5, 1, 1, 50) and torch.equal(small.view(5, 1, 50), y[:, :1, :50])
