@@ -412,9 +412,10 @@ int noise_wave_normalize(const float* x, float* out, float* mx, int B, long L, v
 int noise_wave_final(const float* y, const float* bias, const float* vad, const float* mx, float* out, int B, int Hy, int Wy,
                      int H, int W, void* stream);
 /* out[t][:D] = LayerNorm(act(y[t] + bias) + res[t]) * gamma + beta (models.py:88-92, :109-118, :214); bias / res may be
- * null, relu != 0 applies max(., 0) before the residual, gamma == beta == null skips the normalisation; D <= 1024 */
+ * null, relu != 0 applies max(., 0) before the residual, gamma == beta == null skips the normalisation; pre (optional,
+ * [M][D]) receives the LayerNorm's input for the backward pass; D <= 1024 */
 int noise_tok_epilogue(const float* y, int ldy, const float* bias, int relu, const float* res, int ldr, const float* gamma,
-                       const float* beta, float eps, float* out, int ldo, long M, int D, void* stream);
+                       const float* beta, float eps, float* out, int ldo, float* pre, long M, int D, void* stream);
 /* ScaledDotProductAttention (models.py:14-36): q, k, v [B*n][ld] with head h in columns [h*dk, (h+1)*dk), dk <= 64, any n;
  * out [B*n][ldo] = softmax(q k^T / temperature) (* keep * keep_scale) v; keep [B][H][n][n] bytes (0 = dropped) or null */
 int noise_tok_attention(const float* q, const float* k, const float* v, int ld, const unsigned char* keep, float keep_scale,
@@ -422,6 +423,43 @@ int noise_tok_attention(const float* q, const float* k, const float* v, int ld, 
 /* vad[b] = x[b, token 0, :D] . w + bias[0] (models.py:601); x [B][tokens_per_clip][ld] */
 int noise_tok_vad(const float* x, int ld, long tokens_per_clip, const float* w, const float* bias, float* vad, int B, int D,
                   void* stream);
+
+/* ---- shape-generic backward: with noise_dw3x3_bwd, noise_first_conv_wgrad and noise_bn_bwd above these differentiate the
+ * generic forward, i.e. the waveform-domain training step (models.py:641-685 on the layer stack of :1096-1218).  Gradients
+ * of a convolution's raw output come in the lazy form (dz, y_out, coef3) that noise_bn_bwd leaves; coef3 == NULL: dz ---- */
+/* out[c] = sum over rows of slab [rows][cols] (the fixed-order fold behind every reduction below) */
+int noise_gen_slab_reduce(const float* slab, int rows, long cols, float* out, void* stream);
+/* 1x1 layer (models.py:371-381, :395-396): g_in [npix][Cin] = dy [npix][Cout] x Wt^T, Wt = weight transposed [Cin][ldw] */
+int noise_gen_pw_dgrad(const float* dz, const float* y_out, const float* coef3, const float* Wt, int ldw, float* g_in,
+                       long npix, int Cout, int Cin, void* stream);
+/* dW [Cout][Cin] = sum_p dy[p] (x) a[p], a = the layer's lazily normalised input; slab: noise_gen_pw_wgrad_rows() x Cout*Cin */
+int noise_gen_pw_wgrad_rows(long npix, int Cout, int Cin);
+int noise_gen_pw_wgrad(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,
+                       int a_relu6, float* dw, float* slab, long npix, int Cout, int Cin, void* stream);
+/* out[c] = sum_m x[m][c] (bias gradients); slab: 256 x N floats */
+int noise_gen_colsum(const float* x, int ld, long M, int N, float* out, float* slab, void* stream);
+/* out = h > 0 ? g : 0 over n floats (n % 4 == 0): backward of the feed-forward ReLU (models.py:112) */
+int noise_gen_relu_bwd(const float* g, const float* h, float* out, long n, void* stream);
+/* dst [B][Hd][Wd][C], src [B][Hs][Ws][C]: dst[:, Hd-Hs:, Wd-Ws:, :] += src (gradient of `x + skip[..., -h:, -w:]`, :608) */
+int noise_gen_add_cropped(float* dst, const float* src, int B, int Hd, int Wd, int Hs, int Ws, int C, void* stream);
+/* LayerNorm backward (models.py:90, :116, :214): out = d/dr of LayerNorm(r) against g (+ add); dgamma [D] followed by dbeta
+ * [D] in one buffer; slab: noise_gen_ln_bwd_rows(M) x 2D floats; D <= 1024 */
+int noise_gen_ln_bwd_rows(long M);
+int noise_gen_ln_bwd(const float* g, const float* r, const float* gamma, float eps, const float* add, float* out, float* dgamma,
+                     float* dbeta, float* slab, long M, int D, void* stream);
+/* backward of noise_tok_attention (same layouts; o = its output, go = the gradient of o): dq, dk, dv laid out like q, k, v;
+ * stats: B*H*n*3 floats of workspace */
+int noise_gen_attn_bwd(const float* q, const float* k, const float* v, int ld, const unsigned char* keep, float keep_scale,
+                       const float* o, const float* go, int ldo, float* dq, float* dk, float* dv, float* stats, int B, int n, int H,
+                       int dk_, float temperature, void* stream);
+/* VAD head (models.py:601): gx[b][token 0][:D] += dvad[b] * w, dw[d] = sum_b dvad[b] x[b][token 0][d], db = sum_b dvad[b] */
+int noise_gen_vad_bwd(const float* x, float* gx, int ld, long tokens_per_clip, const float* w, const float* dvad, float* dw,
+                      float* db, int B, int D, void* stream);
+/* last layer (models.py:1164-1171), C -> 1 transposed 3x3 stride 2: dout [B][2Hi-1][2Wi-1] (zero outside the crop), a
+ * [B][Hi][Wi][C] plain; g like a, dw (C,1,3,3); slab: noise_gen_last_bwd_rows() x 9C floats */
+int noise_gen_last_bwd_rows(void);
+int noise_gen_last_convT_bwd(const float* dout, const float* a, const float* w, float* g, float* dw, float* slab, int B, int Hi,
+                             int Wi, int C, void* stream);
 
 /* ---- micro-benchmarks of the two rooflines (no counterpart in the reference; not on the product path) ----------- */
 /* dst = src (n floats, n % 4 == 0): 8 * n bytes of HBM traffic */

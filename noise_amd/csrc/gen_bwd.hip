@@ -1,0 +1,579 @@
+// Shape-generic backward kernels: with noise_gen_pw_dgrad (ofa.hip), noise_dw3x3_bwd / noise_first_conv_wgrad (conv.hip)
+// and noise_bn_bwd (bn.hip) they differentiate the generic forward of generic.py, i.e. the training step of the
+// waveform-domain U-Net (train/models.py:641-685 on the layer stack of :1096-1218).  Activations are NHWC fp32, token
+// matrices row-major [tokens][features]; gradients of a conv output arrive in the lazy form of lazy.h (dz, y, coef3).
+// Every reduction over pixels or tokens goes through per-workgroup partial rows (`slab`) folded in a fixed order by
+// noise_gen_slab_reduce, so results do not depend on scheduling.
+#include "lazy.h"
+
+namespace {
+
+// out[c] = sum_r slab[r][c]
+__global__ __launch_bounds__(256) void gen_slab_reduce_kernel(const float* __restrict__ slab, int rows, long cols,
+                                                              float* __restrict__ out) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += slab[(size_t)r * cols + c];
+  out[c] = s;
+}
+
+// ---- weight gradient of a 1x1 layer: dW[co][ci] = sum_p dy[p][co] a[p][ci] ------------------------------------------------
+// A workgroup owns a 64 x 64 block of dW (blockIdx.x, blockIdx.y) and walks 64-pixel tiles from blockIdx.z: both
+// operands are staged in LDS with their lazy transforms applied, wave w multiplies output-channel tile w with the four
+// input-channel tiles (v_mfma_f32_16x16x4_f32, k = pixels).  Partial blocks go to slab[blockIdx.z][Cout][Cin].
+constexpr int WGR_P = 68;
+
+__global__ __launch_bounds__(256) void gen_pw_wgrad_kernel(LazyGrad G, LazySrc A, float* __restrict__ slab, long npix, int N,
+                                                           int K) {
+  __shared__ float dys[64 * WGR_P];
+  __shared__ float as[64 * WGR_P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+  const int cq = tid & 15, r0 = tid >> 4;
+  const int co = co0 + 4 * cq, ci = ci0 + 4 * cq;
+  const bool von = co < N, vok = ci < K;
+  const int coc = von ? co : 0, cic = vok ? ci : 0;
+  const bool affine = G.coef3 != nullptr;
+  float4 gs = f4(1.f), k1h = f4(0.f), k1l = f4(0.f), a2 = f4(0.f), mh = f4(0.f), ml = f4(0.f);
+  if (affine) {
+    gs = ld4(G.coef3 + coc);
+    k1h = ld4(G.coef3 + N + coc);
+    k1l = ld4(G.coef3 + 2 * N + coc);
+    a2 = ld4(G.coef3 + 3 * N + coc);
+    mh = ld4(G.coef3 + 4 * N + coc);
+    ml = ld4(G.coef3 + 5 * N + coc);
+  }
+  const float4 asc = A.coef ? ld4(A.coef + cic) : f4(1.f), ash = A.coef ? ld4(A.coef + K + cic) : f4(0.f);
+  const float alo = A.relu6 ? 0.f : -INFINITY, ahi = A.relu6 ? 6.f : INFINITY;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (npix + 63) / 64;
+  for (long tile = blockIdx.z; tile < ntiles; tile += gridDim.z) {
+    float4 rz[4], ry[4], ra[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long pix = tile * 64 + r0 + 16 * i;
+      const size_t pc = (size_t)(pix < npix ? pix : npix - 1);
+      rz[i] = ld4(G.dz + pc * N + coc);
+      ry[i] = affine ? ld4(G.y + pc * N + coc) : f4(0.f);
+      ra[i] = ld4(A.y + pc * K + cic);
+    }
+    __syncthreads();   // the previous tile's products have read the staged operands
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool in = tile * 64 + r0 + 16 * i < npix;
+      const float4 dy = affine ? fma4(a2, sub4(sub4(ry[i], mh), ml), gs * sub4(sub4(rz[i], k1h), k1l)) : rz[i];
+      st4(dys + (r0 + 16 * i) * WGR_P + 4 * cq, (in && von) ? dy : f4(0.f));
+      st4(as + (r0 + 16 * i) * WGR_P + 4 * cq, (in && vok) ? clamp4(fma4(ra[i], asc, ash), alo, ahi) : f4(0.f));
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int pp = 4 * s + q;
+      const float dv = dys[pp * WGR_P + 16 * wave + p];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, as[pp * WGR_P + 16 * j + p], acc[j], 0, 0, 0);
+    }
+  }
+  float* blk = slab + (size_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = co0 + 16 * wave + 4 * q + e, i = ci0 + 16 * j + p;
+      if (o < N && i < K) blk[(size_t)o * K + i] = acc[j][e];
+    }
+  }
+}
+
+// ---- column sums of a row-major matrix (bias gradients): slab[blockIdx.x][N] ----------------------------------------------
+__global__ __launch_bounds__(256) void gen_colsum_kernel(const float* __restrict__ x, int ld, long M, int N,
+                                                         float* __restrict__ slab) {
+  __shared__ float red[256];
+  const long chunk = (M + gridDim.x - 1) / gridDim.x;
+  const long m0 = (long)blockIdx.x * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
+  if (N >= 64) {   // a thread owns columns tid, tid + 256, ...
+    for (int c = threadIdx.x; c < N; c += 256) {
+      float s = 0.f;
+      for (long m = m0; m < m1; ++m) s += x[(size_t)m * ld + c];
+      slab[(size_t)blockIdx.x * N + c] = s;
+    }
+  } else {         // narrow matrices: the threads split the rows, then fold in a fixed order
+    for (int c = 0; c < N; ++c) {
+      float s = 0.f;
+      for (long m = m0 + threadIdx.x; m < m1; m += 256) s += x[(size_t)m * ld + c];
+      red[threadIdx.x] = s;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) slab[(size_t)blockIdx.x * N + c] = red[0];
+      __syncthreads();
+    }
+  }
+}
+
+// ---- elementwise pieces ---------------------------------------------------------------------------------------------------------
+// out = h > 0 ? g : 0   (backward of the feed-forward ReLU, models.py:112)
+__global__ __launch_bounds__(256) void gen_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                           float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 gv = ld4(g + 4 * i), hv = ld4(h + 4 * i);
+    st4(out + 4 * i, make_float4(hv.x > 0.f ? gv.x : 0.f, hv.y > 0.f ? gv.y : 0.f, hv.z > 0.f ? gv.z : 0.f, hv.w > 0.f ? gv.w : 0.f));
+  }
+}
+
+// dst[b][Hd - Hs + h][Wd - Ws + w][:] += src[b][h][w][:]   (gradient of `x + skip[..., -h:, -w:]`, models.py:608, and plain sums)
+__global__ __launch_bounds__(256) void gen_add_cropped_kernel(float* __restrict__ dst, const float* __restrict__ src, int B,
+                                                              int Hd, int Wd, int Hs, int Ws, int C4) {
+  const long n = (long)B * Hs * Ws * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % Ws);
+    t /= Ws;
+    const int h = (int)(t % Hs), b = (int)(t / Hs);
+    float* d = dst + ((((size_t)b * Hd + (Hd - Hs + h)) * Wd + (Wd - Ws + w)) * C4 + c) * 4;
+    st4(d, ld4(d) + ld4(src + 4 * i));
+  }
+}
+
+// ---- LayerNorm backward (models.py:90, :116, :214): one wave per token ----------------------------------------------------
+// y = (r - mean) * rstd * gamma + beta;  dr = rstd * (g' - mean(g') - xhat * mean(g' xhat)), g' = g * gamma  (+ add);
+// per-workgroup partial sums of g * xhat and g go to slab[blockIdx.x][2D].
+constexpr int LNB_PER = 16;
+
+__global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict__ g, const float* __restrict__ r,
+                                                         const float* __restrict__ gamma, float eps,
+                                                         const float* __restrict__ add, float* __restrict__ out,
+                                                         float* __restrict__ slab, long M, int D) {
+  __shared__ float red[4 * 2 * 64 * LNB_PER];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[LNB_PER], db[LNB_PER], gm[LNB_PER];
+#pragma unroll
+  for (int j = 0; j < LNB_PER; ++j) {
+    dg[j] = db[j] = 0.f;
+    gm[j] = lane + 64 * j < D ? gamma[lane + 64 * j] : 0.f;
+  }
+  for (long t = (long)blockIdx.x * 4 + wave; t < M; t += (long)gridDim.x * 4) {
+    float v[LNB_PER], gv[LNB_PER];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_PER; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = i < D ? r[(size_t)t * D + i] : 0.f;
+      gv[j] = i < D ? g[(size_t)t * D + i] : 0.f;
+      s += v[j];
+    }
+    const float mean = wave_reduce_sum(s) / (float)D;
+    float qq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_PER; ++j) {
+      const float dlt = v[j] - mean;
+      qq += (lane + 64 * j < D) ? dlt * dlt : 0.f;
+    }
+    const float rstd = 1.f / sqrtf(wave_reduce_sum(qq) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_PER; ++j) {
+      const bool in = lane + 64 * j < D;
+      const float xh = in ? (v[j] - mean) * rstd : 0.f;
+      const float gp = gv[j] * gm[j];
+      s1 += gp;
+      s2 += gp * xh;
+      dg[j] += gv[j] * xh;
+      db[j] += gv[j];
+      v[j] = xh;
+      gv[j] = gp;
+    }
+    const float m1 = wave_reduce_sum(s1) / (float)D, m2 = wave_reduce_sum(s2) / (float)D;
+#pragma unroll
+    for (int j = 0; j < LNB_PER; ++j) {
+      const int i = lane + 64 * j;
+      if (i < D) {
+        float o = rstd * (gv[j] - m1 - v[j] * m2);
+        if (add) o += add[(size_t)t * D + i];
+        out[(size_t)t * D + i] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LNB_PER; ++j) {
+    red[((wave * 2 + 0) * LNB_PER + j) * 64 + lane] = dg[j];
+    red[((wave * 2 + 1) * LNB_PER + j) * 64 + lane] = db[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int k = i / D, c = i - k * D, j = c >> 6, l = c & 63;
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) sum += red[((wv * 2 + k) * LNB_PER + j) * 64 + l];
+    slab[(size_t)blockIdx.x * 2 * D + i] = sum;
+  }
+}
+
+// ---- attention backward (models.py:26-36): two passes, both recompute the scores ----------------------------------------------
+// Pass Q (a thread owns a query): softmax statistics (max, sum) and D_i = dO_i . O_i, then dq_i = sum_j ds_ij k_j / T with
+// ds_ij = p_ij (dp_ij - D_i), dp_ij = keep_ij * keep_scale * (dO_i . v_j).  The three statistics are kept for pass KV (a
+// thread owns a key): dv_j = sum_i p_ij keep_ij keep_scale dO_i, dk_j = sum_i ds_ij q_i / T.  No atomics.
+constexpr int ATB_KB = 128;
+
+template <int DKP>
+__global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, int ld,
+                                                             const unsigned char* __restrict__ keep, float keep_scale,
+                                                             const float* __restrict__ o, const float* __restrict__ go, int ldo,
+                                                             float* __restrict__ dq, float* __restrict__ stats, int n, int H,
+                                                             int dk, float inv_temp) {
+  __shared__ float Ks[ATB_KB * DKP];
+  __shared__ float Vs[ATB_KB * DKP];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  const size_t row0 = (size_t)b * n, ic = live ? i : 0;
+  float qr[DKP], gr[DKP], acc[DKP];
+  float Di = 0.f;
+#pragma unroll
+  for (int d = 0; d < DKP; ++d) {
+    const bool in = live && d < dk;
+    qr[d] = in ? q[(row0 + ic) * ld + h * dk + d] * inv_temp : 0.f;
+    gr[d] = in ? go[(row0 + ic) * ldo + h * dk + d] : 0.f;
+    Di = fmaf(gr[d], in ? o[(row0 + ic) * ldo + h * dk + d] : 0.f, Di);
+    acc[d] = 0.f;
+  }
+  const unsigned char* kp = keep ? keep + (((size_t)b * H + h) * n + ic) * n : nullptr;
+  float m = -INFINITY, l = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float rl = pass ? 1.f / l : 0.f;
+    for (int j0 = 0; j0 < n; j0 += ATB_KB) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < ATB_KB * DKP; e += 256) {
+        const int j = e / DKP, d = e - j * DKP;
+        const bool in = j0 + j < n && d < dk;
+        Ks[e] = in ? k[(row0 + j0 + j) * ld + h * dk + d] : 0.f;
+        if (pass) Vs[e] = in ? v[(row0 + j0 + j) * ld + h * dk + d] : 0.f;
+      }
+      __syncthreads();
+      const int jn = n - j0 < ATB_KB ? n - j0 : ATB_KB;
+      for (int j = 0; j < jn; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
+        if (pass == 0) {
+          if (s > m) {
+            l *= expf(m - s);
+            m = s;
+          }
+          l += expf(s - m);
+        } else {
+          const float pj = expf(s - m) * rl;
+          float dp = 0.f;
+#pragma unroll
+          for (int d = 0; d < DKP; ++d) dp = fmaf(gr[d], Vs[j * DKP + d], dp);
+          if (kp) dp = kp[j0 + j] ? dp * keep_scale : 0.f;
+          const float ds = pj * (dp - Di);
+#pragma unroll
+          for (int d = 0; d < DKP; ++d) acc[d] = fmaf(ds, Ks[j * DKP + d], acc[d]);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < DKP; ++d)
+      if (d < dk) dq[(row0 + i) * ld + h * dk + d] = acc[d] * inv_temp;
+    float* st = stats + (((size_t)b * H + h) * n + i) * 3;
+    st[0] = m;
+    st[1] = 1.f / l;
+    st[2] = Di;
+  }
+}
+
+template <int DKP, int QB>
+__global__ __launch_bounds__(256) void gen_attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, int ld,
+                                                              const unsigned char* __restrict__ keep, float keep_scale,
+                                                              const float* __restrict__ go, int ldo,
+                                                              const float* __restrict__ stats, float* __restrict__ dkk,
+                                                              float* __restrict__ dv, int n, int H, int dk, float inv_temp) {
+  __shared__ float Qs[QB * DKP];
+  __shared__ float Gs[QB * DKP];
+  __shared__ float St[QB * 3];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < n;
+  const size_t row0 = (size_t)b * n, jc = live ? j : 0;
+  float kr[DKP], vr[DKP], ak[DKP], av[DKP];
+#pragma unroll
+  for (int d = 0; d < DKP; ++d) {
+    const bool in = live && d < dk;
+    kr[d] = in ? k[(row0 + jc) * ld + h * dk + d] : 0.f;
+    vr[d] = in ? v[(row0 + jc) * ld + h * dk + d] : 0.f;
+    ak[d] = av[d] = 0.f;
+  }
+  const unsigned char* kp = keep ? keep + ((size_t)b * H + h) * n * n + jc : nullptr;
+  for (int i0 = 0; i0 < n; i0 += QB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < QB * DKP; e += 256) {
+      const int i = e / DKP, d = e - i * DKP;
+      const bool in = i0 + i < n && d < dk;
+      Qs[e] = in ? q[(row0 + i0 + i) * ld + h * dk + d] * inv_temp : 0.f;
+      Gs[e] = in ? go[(row0 + i0 + i) * ldo + h * dk + d] : 0.f;
+    }
+    for (int e = threadIdx.x; e < QB * 3; e += 256)
+      St[e] = i0 + e / 3 < n ? stats[(((size_t)b * H + h) * n + i0) * 3 + e] : 0.f;
+    __syncthreads();
+    const int in_ = n - i0 < QB ? n - i0 : QB;
+    for (int i = 0; i < in_; ++i) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DKP; ++d) {
+        s = fmaf(Qs[i * DKP + d], kr[d], s);
+        dp = fmaf(Gs[i * DKP + d], vr[d], dp);
+      }
+      const float pj = expf(s - St[3 * i]) * St[3 * i + 1];
+      float pm = pj;
+      if (kp) {
+        const bool kept = kp[(size_t)(i0 + i) * n] != 0;
+        pm = kept ? pj * keep_scale : 0.f;
+        dp = kept ? dp * keep_scale : 0.f;
+      }
+      const float ds = pj * (dp - St[3 * i + 2]);
+#pragma unroll
+      for (int d = 0; d < DKP; ++d) {
+        av[d] = fmaf(pm, Gs[i * DKP + d], av[d]);
+        ak[d] = fmaf(ds, Qs[i * DKP + d], ak[d]);
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < DKP; ++d) {
+      if (d < dk) {
+        dkk[(row0 + j) * ld + h * dk + d] = ak[d];
+        dv[(row0 + j) * ld + h * dk + d] = av[d];
+      }
+    }
+  }
+}
+
+// ---- VAD head backward (models.py:601): gx[b][token 0][:] += dvad[b] * w; slab-free: one workgroup folds dw and db --------
+__global__ __launch_bounds__(256) void gen_vad_bwd_kernel(const float* __restrict__ x, float* __restrict__ gx, int ld,
+                                                          long tokens_per_clip, const float* __restrict__ w,
+                                                          const float* __restrict__ dvad, float* __restrict__ dw,
+                                                          float* __restrict__ db, int B, int D) {
+  __shared__ float red[256];
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const size_t row = (size_t)b * tokens_per_clip * ld;
+      s = fmaf(dvad[b], x[row + d], s);
+      gx[row + d] += dvad[b] * w[d];
+    }
+    dw[d] = s;
+  }
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) s += dvad[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[0] = red[0];
+}
+
+// ---- last layer backward: C -> 1 transposed 3x3, stride 2, padding 1 (models.py:1164-1171) ----------------------------------
+// out[b][Y][X] = bias + sum_c sum_k a[b][(Y+1-ky)/2][(X+1-kx)/2][c] w[c][k]; given d = dL/dout on the full (2Hi-1) x (2Wi-1)
+// output: g[b][iy][ix][c] = sum_k d[b][2iy-1+ky][2ix-1+kx] w[c][k], dW[c][k] = sum a d.  A thread owns 4 channels of an
+// input pixel; per-workgroup partial dW rows ([9][C]) go to the slab.
+__global__ __launch_bounds__(256) void gen_last_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                           const float* __restrict__ w, float* __restrict__ g,
+                                                           float* __restrict__ slab, int B, int Hi, int Wi, int C, int cl) {
+  extern __shared__ float red[];   // [256][36]
+  const int CG = C >> 2, PL = 256 / cl;
+  const int cgl = threadIdx.x & (cl - 1), pl = threadIdx.x / cl;
+  const bool ok = cgl < CG;
+  const int c = 4 * (ok ? cgl : CG - 1);
+  const int Hy = 2 * Hi - 1, Wy = 2 * Wi - 1;
+  float4 wt[9], dwk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wt[t] = make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
+    dwk[t] = f4(0.f);
+  }
+  const long npix = (long)B * Hi * Wi;
+  for (long px = (long)blockIdx.x * PL + pl; px < npix; px += (long)gridDim.x * PL) {
+    const int ix = (int)(px % Wi);
+    const long t = px / Wi;
+    const int iy = (int)(t % Hi), b = (int)(t / Hi);
+    const float4 av = ok ? ld4(a + (size_t)px * C + c) : f4(0.f);
+    float4 acc = f4(0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int Y = 2 * iy - 1 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int X = 2 * ix - 1 + kx;
+        const bool in = Y >= 0 && Y < Hy && X >= 0 && X < Wy;
+        const float d = in ? dout[((size_t)b * Hy + (in ? Y : 0)) * Wy + (in ? X : 0)] : 0.f;
+        acc = fma4(f4(d), wt[ky * 3 + kx], acc);
+        dwk[ky * 3 + kx] = fma4(f4(d), av, dwk[ky * 3 + kx]);
+      }
+    }
+    if (ok) st4(g + (size_t)px * C + c, acc);
+  }
+  float* mine = red + threadIdx.x * 36;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) st4(mine + 4 * t, dwk[t]);
+  __syncthreads();
+  if (pl == 0 && ok) {
+    for (int t = 0; t < 9; ++t) {
+      float4 s = f4(0.f);
+      for (int r = 0; r < PL; ++r) s = s + ld4(red + (r * cl + threadIdx.x) * 36 + 4 * t);
+      // slab row layout [C][9] like the weight tensor
+      float* row = slab + (size_t)blockIdx.x * 9 * C;
+      row[(c + 0) * 9 + t] = s.x;
+      row[(c + 1) * 9 + t] = s.y;
+      row[(c + 2) * 9 + t] = s.z;
+      row[(c + 3) * 9 + t] = s.w;
+    }
+  }
+}
+
+inline int pow2_lanes(int C) {
+  int cl = 1;
+  while (cl < C / 4 && cl < 64) cl <<= 1;
+  return cl;
+}
+
+}  // namespace
+
+NOISE_EXPORT int noise_gen_slab_reduce(const float* slab, int rows, long cols, float* out, void* stream) {
+  NOISE_REQUIRE(slab && out && rows > 0 && cols > 0, "noise_gen_slab_reduce: bad argument");
+  hipLaunchKernelGGL(gen_slab_reduce_kernel, dim3(noise_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, slab, rows, cols, out);
+  NOISE_CHECK_LAUNCH("noise_gen_slab_reduce");
+  return 0;
+}
+
+// rows of the partial slab noise_gen_pw_wgrad writes for npix pixels (each Cout*Cin floats)
+NOISE_EXPORT int noise_gen_pw_wgrad_rows(long npix, int Cout, int Cin) {
+  const long ntiles = (npix + 63) / 64;
+  long rows = 2048 / ((long)noise_cdiv(Cout, 64) * noise_cdiv(Cin, 64));
+  const long cap = (64L << 20) / ((long)Cout * Cin * 4);   // at most 64 MiB of partials
+  if (rows > cap) rows = cap;
+  if (rows > ntiles) rows = ntiles;
+  return rows < 1 ? 1 : (int)rows;
+}
+
+NOISE_EXPORT int noise_gen_pw_wgrad(const float* dz, const float* y_out, const float* coef3, const float* a_y,
+                                    const float* a_coef, int a_relu6, float* dw, float* slab, long npix, int Cout, int Cin,
+                                    void* stream) {
+  NOISE_REQUIRE(dz && a_y && dw && slab && (coef3 == nullptr || y_out != nullptr), "noise_gen_pw_wgrad: null pointer");
+  NOISE_REQUIRE(npix > 0 && Cout >= 4 && Cout % 4 == 0 && Cin >= 4 && Cin % 4 == 0, "noise_gen_pw_wgrad: widths must be "
+                "multiples of 4 (Cout %d, Cin %d)", Cout, Cin);
+  const int rows = noise_gen_pw_wgrad_rows(npix, Cout, Cin);
+  const dim3 grid(noise_cdiv(Cout, 64), noise_cdiv(Cin, 64), rows);
+  NOISE_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "noise_gen_pw_wgrad: layer too wide");
+  const LazyGrad G{dz, y_out, coef3};
+  const LazySrc A{a_y, a_coef, a_relu6};
+  hipLaunchKernelGGL(gen_pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, G, A, slab, npix, Cout, Cin);
+  NOISE_CHECK_LAUNCH("noise_gen_pw_wgrad");
+  return noise_gen_slab_reduce(slab, rows, (long)Cout * Cin, dw, stream);
+}
+
+NOISE_EXPORT int noise_gen_colsum(const float* x, int ld, long M, int N, float* out, float* slab, void* stream) {
+  NOISE_REQUIRE(x && out && slab && M > 0 && N > 0 && ld >= N, "noise_gen_colsum: bad argument");
+  const int rows = (int)(M < 256 ? M : 256);   // slab: 256 x N floats
+  hipLaunchKernelGGL(gen_colsum_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, slab);
+  NOISE_CHECK_LAUNCH("noise_gen_colsum");
+  return noise_gen_slab_reduce(slab, rows, N, out, stream);
+}
+
+NOISE_EXPORT int noise_gen_relu_bwd(const float* g, const float* h, float* out, long n, void* stream) {
+  NOISE_REQUIRE(g && h && out && n > 0 && n % 4 == 0, "noise_gen_relu_bwd: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(gen_relu_bwd_kernel, dim3(noise_grid(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, h, out, n / 4);
+  NOISE_CHECK_LAUNCH("noise_gen_relu_bwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_gen_add_cropped(float* dst, const float* src, int B, int Hd, int Wd, int Hs, int Ws, int C, void* stream) {
+  NOISE_REQUIRE(dst && src, "noise_gen_add_cropped: null pointer");
+  NOISE_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Hd >= Hs && Wd >= Ws && C >= 4 && C % 4 == 0, "noise_gen_add_cropped: bad shape");
+  hipLaunchKernelGGL(gen_add_cropped_kernel, dim3(noise_grid((long)B * Hs * Ws * (C / 4), 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, dst, src, B, Hd, Wd, Hs, Ws, C / 4);
+  NOISE_CHECK_LAUNCH("noise_gen_add_cropped");
+  return 0;
+}
+
+// slab: noise_gen_ln_bwd_rows(M) x 2D floats; dgamma, dbeta: D floats
+NOISE_EXPORT int noise_gen_ln_bwd_rows(long M) { return noise_grid(M, 4 * 16, 1024); }
+
+NOISE_EXPORT int noise_gen_ln_bwd(const float* g, const float* r, const float* gamma, float eps, const float* add, float* out,
+                                  float* dgamma, float* dbeta, float* slab, long M, int D, void* stream) {
+  NOISE_REQUIRE(g && r && gamma && out && dgamma && dbeta && slab, "noise_gen_ln_bwd: null pointer");
+  NOISE_REQUIRE(M > 0 && D > 0 && D <= 64 * LNB_PER, "noise_gen_ln_bwd: 1 <= D <= %d (got %d)", 64 * LNB_PER, D);
+  // a slab row is [sum g*xhat (D) | sum g (D)] and is folded in one go
+  NOISE_REQUIRE(dbeta == dgamma + D, "noise_gen_ln_bwd: dbeta must follow dgamma in memory (dgamma + D)");
+  const int rows = noise_gen_ln_bwd_rows(M);
+  hipLaunchKernelGGL(gen_ln_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, r, gamma, eps, add, out, slab, M, D);
+  NOISE_CHECK_LAUNCH("noise_gen_ln_bwd");
+  return noise_gen_slab_reduce(slab, rows, 2L * D, dgamma, stream);
+}
+
+// q, k, v, dq, dk, dv: [B*n][ld] with head h in columns [h*dk, (h+1)*dk); o, go: [B*n][ldo]; stats: B*H*n*3 floats
+NOISE_EXPORT int noise_gen_attn_bwd(const float* q, const float* k, const float* v, int ld, const unsigned char* keep,
+                                    float keep_scale, const float* o, const float* go, int ldo, float* dq, float* dk_, float* dv,
+                                    float* stats, int B, int n, int H, int dk, float temperature, void* stream) {
+  NOISE_REQUIRE(q && k && v && o && go && dq && dk_ && dv && stats, "noise_gen_attn_bwd: null pointer");
+  NOISE_REQUIRE(B > 0 && n > 0 && H > 0 && dk > 0 && dk <= 64, "noise_gen_attn_bwd: head size must be in 1..64 (got %d)", dk);
+  NOISE_REQUIRE(B <= 65535 && H <= 65535 && ld >= H * dk && ldo >= H * dk && temperature > 0.f, "noise_gen_attn_bwd: bad shape");
+  const dim3 grid(noise_cdiv(n, 256), H, B);
+  hipStream_t st = (hipStream_t)stream;
+  const float it = 1.f / temperature;
+#define ATB_CASE(P, QB)                                                                                                   \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL(gen_attn_bwd_q_kernel<P>, grid, dim3(256), 0, st, q, k, v, ld, keep, keep_scale, o, go, ldo, dq,    \
+                       stats, n, H, dk, it);                                                                              \
+    hipLaunchKernelGGL((gen_attn_bwd_kv_kernel<P, QB>), grid, dim3(256), 0, st, q, k, v, ld, keep, keep_scale, go, ldo,    \
+                       stats, dk_, dv, n, H, dk, it);                                                                     \
+  } while (0)
+  if (dk <= 8) ATB_CASE(8, 128);
+  else if (dk <= 16) ATB_CASE(16, 128);
+  else if (dk <= 24) ATB_CASE(24, 128);
+  else if (dk <= 32) ATB_CASE(32, 128);
+  else ATB_CASE(64, 64);
+#undef ATB_CASE
+  NOISE_CHECK_LAUNCH("noise_gen_attn_bwd");
+  return 0;
+}
+
+NOISE_EXPORT int noise_gen_vad_bwd(const float* x, float* gx, int ld, long tokens_per_clip, const float* w, const float* dvad,
+                                   float* dw, float* db, int B, int D, void* stream) {
+  NOISE_REQUIRE(x && gx && w && dvad && dw && db && B > 0 && D > 0 && ld >= D, "noise_gen_vad_bwd: bad argument");
+  hipLaunchKernelGGL(gen_vad_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, gx, ld, tokens_per_clip, w, dvad, dw, db,
+                     B, D);
+  NOISE_CHECK_LAUNCH("noise_gen_vad_bwd");
+  return 0;
+}
+
+// dout [B][2Hi-1][2Wi-1] (zero outside the cropped region), a [B][Hi][Wi][C] plain, w (C,1,3,3); g like a; dw (C,1,3,3);
+// slab: noise_gen_last_bwd_rows() x 9C floats
+NOISE_EXPORT int noise_gen_last_bwd_rows(void) { return 1024; }
+
+NOISE_EXPORT int noise_gen_last_convT_bwd(const float* dout, const float* a, const float* w, float* g, float* dw, float* slab,
+                                          int B, int Hi, int Wi, int C, void* stream) {
+  NOISE_REQUIRE(dout && a && w && g && dw && slab, "noise_gen_last_convT_bwd: null pointer");
+  NOISE_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C >= 4 && C % 4 == 0 && C <= 256, "noise_gen_last_convT_bwd: bad shape (C a multiple "
+                "of 4, at most 256)");
+  const int cl = pow2_lanes(C);
+  const int rows = noise_grid((long)B * Hi * Wi, 256 / cl * 4, 1024);
+  hipLaunchKernelGGL(gen_last_bwd_kernel, dim3(rows), dim3(256), 256 * 36 * sizeof(float), (hipStream_t)stream, dout, a, w, g,
+                     slab, B, Hi, Wi, C, cl);
+  NOISE_CHECK_LAUNCH("noise_gen_last_convT_bwd");
+  return noise_gen_slab_reduce(slab, rows, 9L * C, dw, stream);
+}

@@ -246,9 +246,12 @@ struct PwGDims {
 };
 constexpr int PWG_KC = 32, PWG_PITCH = 36;
 
-template <int NT>
-__global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* __restrict__ W, float* __restrict__ out,
-                                                     float* __restrict__ slab, PwGDims d) {
+// GRAD: the input operand is a lazily evaluated gradient (dz, y, coef3 of lazy.h) instead of a lazily normalised
+// activation, which makes the same product the input gradient of a 1x1 layer (W = the layer's weight transposed).
+// slab == nullptr skips the statistics.
+template <int NT, bool GRAD>
+__global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad, const float* __restrict__ W,
+                                                     float* __restrict__ out, float* __restrict__ slab, PwGDims d) {
   __shared__ float As[64 * PWG_PITCH];
   __shared__ float Ws[NT * 16 * PWG_PITCH];
   __shared__ float red[4 * 2 * NT * 16];
@@ -265,6 +268,9 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* _
   // staging maps: a thread moves 2 float4 of the input chunk (64 pixels x 8 channel quads) and NT/2 of the weight chunk
   const int kq = tid & 7, r0 = tid >> 3;
   float4 ra[2], rsc, rsh, rw[NT / 2];
+  float4 rb[GRAD ? 2 : 1], rg[GRAD ? 4 : 1];   // GRAD: raw layer output and the remaining coefficient vectors
+  const bool affine = GRAD && grad.coef3 != nullptr;
+  const float* const ay = GRAD ? grad.dz : src.y;
   unsigned vin = 0;   // bit i: ra[i] holds an existing element; bit 8+i: rw[i] does
   auto fetch = [&](long tile, int ch) {
     const int kk = ch * PWG_KC + 4 * kq;
@@ -275,11 +281,21 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* _
     for (int i = 0; i < 2; ++i) {
       const long pix = tile * 64 + r0 + 32 * i;
       const bool in = kin && pix < d.npix;
-      ra[i] = ld4(src.y + (size_t)(in ? pix : 0) * K + kc);
+      ra[i] = ld4(ay + (size_t)(in ? pix : 0) * K + kc);
+      if (GRAD) rb[i] = affine ? ld4(grad.y + (size_t)(in ? pix : 0) * K + kc) : f4(0.f);
       vin |= in ? (1u << i) : 0u;
     }
-    rsc = src.coef ? ld4(src.coef + kc) : f4(1.f);
-    rsh = src.coef ? ld4(src.coef + K + kc) : f4(0.f);
+    if (GRAD) {   // dy = s*((dz - k1_hi) - k1_lo) + a2*((y - mean_hi) - mean_lo)
+      rsc = affine ? ld4(grad.coef3 + kc) : f4(1.f);
+      rsh = affine ? ld4(grad.coef3 + 3 * K + kc) : f4(0.f);
+      rg[0] = affine ? ld4(grad.coef3 + K + kc) : f4(0.f);
+      rg[1] = affine ? ld4(grad.coef3 + 2 * K + kc) : f4(0.f);
+      rg[2] = affine ? ld4(grad.coef3 + 4 * K + kc) : f4(0.f);
+      rg[3] = affine ? ld4(grad.coef3 + 5 * K + kc) : f4(0.f);
+    } else {
+      rsc = src.coef ? ld4(src.coef + kc) : f4(1.f);
+      rsh = src.coef ? ld4(src.coef + K + kc) : f4(0.f);
+    }
 #pragma unroll
     for (int i = 0; i < NT / 2; ++i) {
       const int nr = r0 + 32 * i;
@@ -297,7 +313,9 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* _
     // memory round trip runs under this chunk's matrix products
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float4 v = clamp4(fma4(ra[i], rsc, rsh), alo, ahi);
+      float4 v;
+      if (GRAD) v = fma4(rsh, sub4(sub4(rb[i], rg[2]), rg[3]), rsc * sub4(sub4(ra[i], rg[0]), rg[1]));
+      else v = clamp4(fma4(ra[i], rsc, rsh), alo, ahi);
       st4(As + (r0 + 32 * i) * PWG_PITCH + 4 * kq, ((vin >> i) & 1u) ? v : f4(0.f));
     }
 #pragma unroll
@@ -338,6 +356,7 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, const float* _
     tile = ntile;
     ch = nch;
   }
+  if (slab == nullptr) return;
   // statistics: over the 16 pixel lanes that share q, then over the 4 waves
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
@@ -554,12 +573,38 @@ NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src
   int gy = pixel_rows(ntiles, 1);
   const int want = noise_cdiv(2048, gx);   // few enough pixel rows that gx x rows stays near two rounds of the GPU
   if (gy > want) gy = want;
+  const LazyGrad none{nullptr, nullptr, nullptr};
   if (wide)
-    hipLaunchKernelGGL(ofa_pw_kernel<8>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
+    hipLaunchKernelGGL((ofa_pw_kernel<8, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d);
   else
-    hipLaunchKernelGGL(ofa_pw_kernel<4>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, W, out, slab, d);
+    hipLaunchKernelGGL((ofa_pw_kernel<4, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d);
   *rows = gy;
   NOISE_CHECK_LAUNCH("noise_ofa_pw");
+  return 0;
+}
+
+// Input gradient of a 1x1 layer: g_in [npix][Cin] = dy [npix][Cout] x Wt[:Cin, :Cout]^T with Wt = the layer's weight
+// transposed (row stride ldw) and dy the lazily evaluated gradient (dz, y_out, coef3); coef3 == NULL: dy = dz.
+NOISE_EXPORT int noise_gen_pw_dgrad(const float* dz, const float* y_out, const float* coef3, const float* Wt, int ldw,
+                                    float* g_in, long npix, int Cout, int Cin, void* stream) {
+  NOISE_REQUIRE(dz && Wt && g_in && (coef3 == nullptr || y_out != nullptr), "noise_gen_pw_dgrad: null pointer");
+  NOISE_REQUIRE(npix > 0 && Cout >= 4 && Cout % 4 == 0 && Cin >= 4 && Cin % 4 == 0 && ldw >= Cout && ldw % 4 == 0,
+                "noise_gen_pw_dgrad: widths and the weight row stride must be multiples of 4 (Cout %d, Cin %d, stride %d)", Cout,
+                Cin, ldw);
+  const LazySrc none{nullptr, nullptr, 0};
+  const LazyGrad grad{dz, y_out, coef3};
+  const PwGDims d{npix, Cout, Cin, ldw};
+  const long ntiles = (npix + 63) / 64;
+  const bool wide = Cin > 64 && ntiles * noise_cdiv(Cin, 128) >= 512;
+  const int gx = noise_cdiv(Cin, wide ? 128 : 64);
+  int gy = pixel_rows(ntiles, 1);
+  const int want = noise_cdiv(2048, gx);
+  if (gy > want) gy = want;
+  if (wide)
+    hipLaunchKernelGGL((ofa_pw_kernel<8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, nullptr, d);
+  else
+    hipLaunchKernelGGL((ofa_pw_kernel<4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, nullptr, d);
+  NOISE_CHECK_LAUNCH("noise_gen_pw_dgrad");
   return 0;
 }
 

@@ -44,7 +44,8 @@ constexpr int TOK_PER = 16;   // features per lane: D <= 1024
 __global__ __launch_bounds__(256) void tok_epilogue_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ bias,
                                                            int relu, const float* __restrict__ res, int ldr,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, float* __restrict__ out, int ldo, long M, int D) {
+                                                           float eps, float* __restrict__ out, int ldo, float* __restrict__ pre,
+                                                           long M, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long t = (long)blockIdx.x * 4 + wave; t < M; t += (long)gridDim.x * 4) {
     float v[TOK_PER];
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void tok_epilogue_kernel(const float* __restri
       }
       v[j] = x;
       s += x;
+      if (pre != nullptr && i < D) pre[(size_t)t * D + i] = x;   // the LayerNorm's input, kept for the backward pass
     }
     if (gamma != nullptr) {
       const float mean = wave_reduce_sum(s) / (float)D;
@@ -181,14 +183,14 @@ NOISE_EXPORT int noise_wave_final(const float* y, const float* bias, const float
 }
 
 NOISE_EXPORT int noise_tok_epilogue(const float* y, int ldy, const float* bias, int relu, const float* res, int ldr,
-                                    const float* gamma, const float* beta, float eps, float* out, int ldo, long M, int D,
-                                    void* stream) {
+                                    const float* gamma, const float* beta, float eps, float* out, int ldo, float* pre, long M,
+                                    int D, void* stream) {
   NOISE_REQUIRE(y && out, "noise_tok_epilogue: null pointer");
   NOISE_REQUIRE(M > 0 && D > 0 && D <= 64 * TOK_PER, "noise_tok_epilogue: 1 <= D <= %d (got %d)", 64 * TOK_PER, D);
   NOISE_REQUIRE(ldy >= D && ldo >= D && (!res || ldr >= D), "noise_tok_epilogue: row strides shorter than D");
   NOISE_REQUIRE((gamma == nullptr) == (beta == nullptr), "noise_tok_epilogue: LayerNorm needs both weight and bias");
   hipLaunchKernelGGL(tok_epilogue_kernel, dim3(noise_grid(M, 4, 4096)), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, relu,
-                     res, ldr, gamma, beta, eps, out, ldo, M, D);
+                     res, ldr, gamma, beta, eps, out, ldo, pre, M, D);
   NOISE_CHECK_LAUNCH("noise_tok_epilogue");
   return 0;
 }

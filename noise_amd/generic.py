@@ -21,7 +21,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _lib.register({
     "noise_wave_normalize": [_P, _P, _P, _I, _L, _P],
     "noise_wave_final": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "noise_tok_epilogue": [_P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _L, _I, _P],
+    "noise_tok_epilogue": [_P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _L, _I, _P],
     "noise_tok_attention": [_P, _P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _F, _P],
     "noise_tok_vad": [_P, _I, _L, _P, _P, _P, _I, _I, _P],
 })
@@ -156,13 +156,13 @@ class GenericForward:
         return self.apply(y.view(B, Ho, Wo, N), coef, False, res=res, skip=skip)
 
     # ------------------------------------------------------------------ transformer bottleneck (models.py:172-225)
-    def epilogue(self, y, D, bias=None, relu=False, res=None, ln=None):
+    def epilogue(self, y, D, bias=None, relu=False, res=None, ln=None, pre=None):
         M = y.shape[0]
         out = self.new(M, D)
         _lib.call("noise_tok_epilogue", ptr(y), y.shape[1], ptr(bias), int(relu), ptr(res), res.shape[1] if res is not None else 0,
                   ptr(ln.weight) if ln is not None else None, ptr(ln.bias) if ln is not None else None,
-                  float(ln.eps) if ln is not None else 0.0, ptr(out), D, M, D, _lib.stream(),
-                  nbytes=4 * M * D * (2 + (res is not None)))
+                  float(ln.eps) if ln is not None else 0.0, ptr(out), D, ptr(pre), M, D, _lib.stream(),
+                  nbytes=4 * M * D * (2 + (res is not None) + (pre is not None)))
         return out
 
     def linear(self, x, w, K, N):

@@ -198,12 +198,14 @@ def test_tok_epilogue(M, D, relu, res, ln):
     r = torch.randn(M, D, generator=g).to(DEV) if res else None
     gamma, beta = (torch.randn(D, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)) if ln else (None, None)
     out = torch.empty(M, D, device=DEV)
-    _call("noise_tok_epilogue", P(y), D + 4, P(bias), int(relu), P(r), D, P(gamma), P(beta), 1e-6, P(out), D, M, D)
+    pre = torch.empty(M, D, device=DEV)
+    _call("noise_tok_epilogue", P(y), D + 4, P(bias), int(relu), P(r), D, P(gamma), P(beta), 1e-6, P(out), D, P(pre), M, D)
     v = y[:, :D].double() + bias.double()
     if relu:
         v = v.clamp_min(0)
     if res:
         v = v + r.double()
+    assert (pre.double() - v).abs().max() < 1e-6
     if ln:
         v = torch.nn.functional.layer_norm(v, (D,), gamma.double(), beta.double(), 1e-6)
     assert (out.double() - v).abs().max() < 2e-5
