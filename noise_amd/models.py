@@ -344,9 +344,18 @@ class VADMobileNetV2(_LightningModule):
         return self._shared_step(batch, batch_idx, "val")
 
     def training_step(self, batch, batch_idx):
-        raise NotImplementedError("the waveform-domain training step (train/models.py:681-682) has no backward kernels: "
-                                  "`validation_step` evaluates the same loss, `noise_amd.losses` differentiates it with "
-                                  "respect to the enhanced waveform, the U-Net's own backward pass is not built")
+        """Base.training_step (train/models.py:681-682): the loss of `_shared_step` in train mode; `loss.backward()` fills
+        every parameter's `.grad` (the backward pass has already run on the shape-generic kernels)."""
+        from .generic_train import StepFn
+        noisy, clean, _ = batch
+        _lib.require_cuda(noisy, clean)
+        if not self.training:
+            raise RuntimeError("training_step in eval mode: the backward pass implements train-mode BatchNorm only")
+        params = list(self.parameters())
+        loss, all4 = StepFn.apply(self, noisy, clean, *params)
+        self.log_dict({"train_loss": loss, "train_waveform_loss": all4[1], "train_spectral_loss": all4[2],
+                       "train_vad_loss": all4[3]}, on_step=False, on_epoch=True, prog_bar=True, logger=True, sync_dist=True)
+        return loss
 
 
 # ----------------------------------------------------------------------------- autograd bridge

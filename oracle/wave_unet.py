@@ -150,3 +150,27 @@ def shared_step(m, noisy, clean, mr_stft_lambda, fft_sizes, hop_lengths, win_len
                                               clean.reshape(-1, segment).double().numpy(), vad.double().numpy(), mr_stft_lambda,
                                               fft_sizes, hop_lengths, win_lengths)
     return total, parts
+
+
+def train_step(m, noisy, clean, keep_masks, mr_stft_lambda, fft_sizes, hop_lengths, win_lengths, dtype=torch.float32, segment=8000):
+    """Base.training_step (models.py:641-682) in train mode with gradients: ([total, waveform, spectral, vad], {name: grad}).
+    The network runs under autograd in `dtype`; the loss and its gradient with respect to the enhanced waveform and the VAD
+    logits come from the numpy restatement (oracle/mrstft.py) and are chained into the graph."""
+    from . import mrstft
+    noisy = noisy.reshape(-1, 1, 1, segment).to(dtype)
+    clean = clean.reshape(-1, 1, 1, segment)
+    xn, mx = normalize(noisy)
+    assert m.found, "run the padding search first"
+    with torch.enable_grad():
+        filt, vad = _pass(m, xn, True, keep_masks)
+        enhanced = filt * mx
+    total, parts, d_enh, d_vad = mrstft.waveform_loss(enhanced.detach().reshape(-1, segment).double().numpy(),
+                                                      clean.reshape(-1, segment).double().numpy(),
+                                                      vad.detach().double().numpy(), mr_stft_lambda, fft_sizes, hop_lengths,
+                                                      win_lengths)
+    for p in m.parameters():
+        p.grad = None
+    torch.autograd.backward([enhanced, vad], [torch.from_numpy(d_enh).reshape(enhanced.shape).to(dtype),
+                                              torch.from_numpy(d_vad).reshape(vad.shape).to(dtype)])
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    return [total, parts["l1"], parts["mrstft"], parts["vad"]], grads

@@ -52,6 +52,36 @@ for mode in ("eval", "train"):
     print(json.dumps({"wave_unet_forward": {"mode": mode, "clips": B, "samples": L, "ms": round(ms, 3),
                                             "audio_s_per_s": round(B * L / 16000 / ms * 1e3, 1)}}))
 
+# training step (forward + losses + backward; gradients land in .grad, the optimizer is the caller's)
+if L == 8000:
+    net.train()
+    clean = (torch.randn(B, 1, 1, L) * 0.05).clamp(-1, 1).to(dev)
+    for _ in range(2):
+        net.training_step((xd, clean, None), 0).backward()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        net.training_step((xd, clean, None), 0).backward()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    _lib.PROFILE = prof = []
+    net.training_step((xd, clean, None), 0).backward()
+    torch.cuda.synchronize()
+    _lib.PROFILE = None
+    agg = {}
+    for name, nbytes, a, b in prof:
+        r = agg.setdefault(name, [0.0, 0, 0])
+        r[0] += a.elapsed_time(b)
+        r[1] += nbytes
+        r[2] += 1
+    print(f"== training step: {B} segments x {L} samples: {ms:.3f} ms/step, {len(prof)} launches, {B * L / 16000 / ms * 1e3:,.0f} audio-s/s,"
+          f" peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    for name, (t, nb, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        print(f"   {name:26s} {t:8.3f} ms  {n:4d} calls  {nb / 1e6:9.1f} MB  {nb / 1e6 / max(t, 1e-9):8.1f} GB/s")
+    print(json.dumps({"wave_unet_train_step": {"segments": B, "samples": L, "ms": round(ms, 3),
+                                               "audio_s_per_s": round(B * L / 16000 / ms * 1e3, 1)}}))
+
 # CPU oracle on a bounded sample (test infrastructure timed as the baseline, never the product path)
 from oracle import wave_unet as owu
 cpu = VADMobileNetV2(**MG.kwargs(MG.YAML)).eval()

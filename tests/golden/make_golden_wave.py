@@ -44,9 +44,12 @@ def kwargs(cfg):
             for k, v in cfg.items()}
 
 
-def perturb(m, seed):
+def perturb(m, seed, linear_gain=8.0):
     """Move the tensors the constructor leaves trivial (BatchNorm / LayerNorm affine, running statistics, biases) and tame
-    the last layer so the outputs stay of order one; both the generator and the tests call this."""
+    the last layer so the outputs stay of order one; both the generator and the tests call this.  The training fixture
+    keeps the constructor's scale of the Linear layers (`linear_gain=1`): with the larger weights the attention saturates
+    and the decoder's gradients are 20-30 % rounding noise in fp32 (float64 evaluation against the reference's own fp32
+    gradients), which pins nothing."""
     g = torch.Generator().manual_seed(seed + 1000)
     with torch.no_grad():
         for mod in m.modules():
@@ -59,7 +62,7 @@ def perturb(m, seed):
                 mod.weight.copy_(1 + 0.2 * torch.randn(mod.weight.shape, generator=g))
                 mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
             elif isinstance(mod, nn.Linear):
-                mod.weight.mul_(8.0)             # the constructor's std of 0.01 leaves attention and FFN negligible
+                mod.weight.mul_(linear_gain)     # the constructor's std of 0.01 leaves attention and FFN negligible
                 if mod.bias is not None:
                     mod.bias.copy_(0.05 * torch.randn(mod.bias.shape, generator=g))
         m.vad.weight.copy_(0.02 * torch.randn(m.vad.weight.shape, generator=g))    # a gate that is neither 0 nor 1 ...
@@ -73,6 +76,55 @@ def wave(seed, shape):
     x = torch.randn(shape, generator=g) * 0.1
     x[0] *= 3.0                                   # per-clip maxima that differ
     return x.clamp(-1, 1)
+
+
+def train_fixture(models, g9):
+    """G10: one training step (Base.training_step, models.py:641-682) per case: losses, attention keep masks, the gradient
+    of every parameter (whole tensors for the narrow case, per-tensor sums + norms and a few whole tensors for the wide
+    one)."""
+    out = {}
+    for name in ("narrow", "yaml"):
+        cfg, seed, s1, _ = CASES[name]
+        torch.manual_seed(seed)
+        m = models.VADMobileNetV2(**kwargs(cfg))
+        perturb(m, seed, linear_gain=1.0)
+        with torch.no_grad():
+            m.vad.bias.copy_(torch.from_numpy(g9[f"{name}_vad_bias"]))
+        x1 = wave(seed + 2000, s1)
+        clean = torch.from_numpy(g9[f"{name}_val_clean"])
+        m.eval()
+        with torch.no_grad():
+            m(x1.clone())                         # padding search in eval mode: the running statistics stay put
+        m.train()
+        masks = []
+        for lay in m.bottleneck_attention.layer_stack:
+            lay.slf_attn.attention.dropout.register_forward_hook(lambda mod, inp, o: masks.append((o != 0).numpy().copy()))
+        torch.manual_seed(seed + 9)
+        loss = m.training_step((x1.clone(), clean.clone(), None), 0)
+        loss.backward()
+        out[f"{name}_losses"] = np.array([float(loss)] + [m._logged[f"train_{k}"] for k in
+                                                          ("waveform_loss", "spectral_loss", "vad_loss")])
+        for i, k in enumerate(masks):
+            out[f"{name}_keep{i}"] = np.packbits(k.reshape(-1))
+            out[f"{name}_keep{i}_shape"] = np.array(k.shape)
+        names, stats = [], []
+        whole = ("encoder.0.0.weight", "encoder.0.1.weight", "encoder.2.conv.0.0.weight", "encoder.2.conv.1.0.weight",
+                 "encoder.3.conv.2.weight", "decoder.0.conv.1.0.weight", "bottleneck_attention.layer_stack.0.slf_attn.w_qs.weight",
+                 "bottleneck_attention.layer_stack.1.pos_ffn.w_1.bias", "bottleneck_attention.layer_norm.weight", "vad.weight",
+                 "vad.bias", f"decoder.{len(m.decoder) - 1}.0.weight", f"decoder.{len(m.decoder) - 1}.0.bias")
+        for k, p in m.named_parameters():
+            gk = p.grad.double()
+            names.append(k)
+            stats.append([float(gk.sum()), float(gk.abs().sum()), float(gk.norm())])
+            if name == "narrow" or k in whole:
+                out[f"{name}_grad/{k}"] = p.grad.numpy().copy()
+        out[f"{name}_grad_names"] = np.array(names)
+        out[f"{name}_grad_stats"] = np.array(stats)
+        for key in ("encoder.0.1", "decoder.0.conv.3"):
+            out[f"{name}_buf/{key}.running_var"] = dict(m.named_buffers())[key + ".running_var"].numpy().copy()
+        print(name, "train losses", out[f"{name}_losses"], "grad tensors", len(names))
+    np.savez_compressed(os.path.join(OUT, "g10_wave_train.npz"), **out)
+    print("wrote g10_wave_train.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
 
 def main():
@@ -160,6 +212,7 @@ def main():
         out[f"{name}_fresh/decoder.0.conv.3.running_mean"] = fb["decoder.0.conv.3.running_mean"].numpy().copy()
         print(name, "padding", pad, "eval |y|", float(y1.abs().mean()), "train |f|", float(ft.abs().mean()), "eval |f|", float(filt.abs().mean()),
               "vad", vad.flatten().tolist(), "searches", int(fb["encoder.0.1.num_batches_tracked"]))
+    train_fixture(models, out)
     np.savez_compressed(os.path.join(OUT, "g9_wave.npz"), **out)
     print("wrote g9_wave.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 

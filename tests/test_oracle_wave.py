@@ -17,11 +17,11 @@ from oracle import wave_unet as owu  # noqa: E402
 G9 = np.load(os.path.join(HERE, "golden", "g9_wave.npz"))
 
 
-def build(name, dtype=torch.float32):
+def build(name, linear_gain=8.0):
     cfg, seed, _, _ = MG.CASES[name]
     torch.manual_seed(seed)
     m = VADMobileNetV2(**MG.kwargs(cfg))
-    MG.perturb(m, seed)
+    MG.perturb(m, seed, linear_gain)
     with torch.no_grad():
         m.vad.bias.copy_(torch.from_numpy(G9[f"{name}_vad_bias"]))
     return m
@@ -104,3 +104,33 @@ def test_oracle_validation_step(name):
                                    [240, 600, 1200])
     want = G9[f"{name}_val_losses"]
     np.testing.assert_allclose([total, total, parts["l1"], parts["mrstft"], parts["vad"]], want, rtol=2e-5)
+
+
+G10 = np.load(os.path.join(HERE, "golden", "g10_wave_train.npz"))
+
+
+def test_oracle_train_step():
+    """Base.training_step + backward on the narrow case: the oracle in fp32 against the reference's gradients, and a float64
+    evaluation as the yardstick of what fp32 is worth on this step (batch statistics over two clips, ReLU6 masks)."""
+    name = "narrow"
+    cfg = MG.CASES[name][0]
+    masks = []
+    for i in range(2):
+        shape = tuple(int(v) for v in G10[f"{name}_keep{i}_shape"])
+        bits = np.unpackbits(G10[f"{name}_keep{i}"])[:int(np.prod(shape))]
+        masks.append(torch.from_numpy(bits.reshape(shape).astype(np.uint8)))
+    names, stats = list(G10[f"{name}_grad_names"]), G10[f"{name}_grad_stats"]
+    floor = 1e-7 * float(stats[:, 2].max())
+    worst = {}
+    for dt in (torch.float32, torch.float64):
+        m = build(name, linear_gain=1.0).eval()
+        x1, clean = torch.from_numpy(G9[f"{name}_x1"]), torch.from_numpy(G9[f"{name}_val_clean"])
+        owu.forward(m, owu.normalize(x1)[0], False)
+        m.train()
+        losses, grads = owu.train_step(m, x1, clean, masks, cfg.get("mr_stft_lambda", 0.5), [512, 1024, 2048], [50, 120, 240],
+                                       [240, 600, 1200], dtype=dt)
+        np.testing.assert_allclose(losses, G10[f"{name}_losses"], rtol=1e-4)
+        assert list(grads) == names
+        worst[dt] = max(max(float((grads[k].double() - torch.from_numpy(G10[f"{name}_grad/{k}"]).double()).norm()) - floor, 0.0)
+                        / max(nrm, 1e-30) for k, (_, _, nrm) in zip(names, stats))
+    assert worst[torch.float32] < 2e-2 and worst[torch.float64] < 4e-2, worst
