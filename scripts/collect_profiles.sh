@@ -16,10 +16,11 @@ cp $P/infer_hbm_traffic_per_kernel.json profiles/${R}_infer_bf16_hbm_traffic_per
 cp $P/infer_mfma_utilisation.txt profiles/${R}_infer_bf16_mfma_utilisation.txt
 # written by scripts/profile_round_extra.sh
 for f in synth_1024.txt synth_4096.txt stft_accuracy.txt walk_occupancy.txt synth_hbm_traffic.txt synth_hbm_traffic_per_kernel.json \
-         measured_peaks.json other_configs.json augment_256x10s.txt ofa_forward.txt; do
+         measured_peaks.json other_configs.json augment_256x10s.txt ofa_forward.txt wave_unet.txt; do
   [ -f $P/$f ] && cp $P/$f profiles/${R}_$f
 done
 [ -f $P/skt/p_kernel_stats.csv ] && cp $P/skt/p_kernel_stats.csv profiles/${R}_synth_kernel_stats.csv
+[ -f $P/wkt/p_kernel_stats.csv ] && cp $P/wkt/p_kernel_stats.csv profiles/${R}_wave_unet_kernel_stats.csv
 A=gpurun_out/prof_aug
 [ -f $A/kt/p_kernel_stats.csv ] && cp $A/kt/p_kernel_stats.csv profiles/${R}_augment_kernel_stats.csv
 [ -f $A/hbm_traffic.txt ] && cp $A/hbm_traffic.txt profiles/${R}_augment_hbm_traffic.txt

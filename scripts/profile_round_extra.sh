@@ -19,6 +19,9 @@ timeout -k 10 300 python3 scripts/measure_configs.py > $O/other_configs.json 2> 
 timeout -k 10 200 python3 scripts/bench_augment.py 256 1.0 --cpu > $O/augment_256x10s.txt 2>&1
 timeout -k 10 200 python3 scripts/bench_ofa.py 64 7 > $O/ofa_forward.txt 2>&1
 timeout -k 10 200 python3 scripts/bench_ofa.py 64 3 >> $O/ofa_forward.txt 2>&1
+timeout -k 10 300 python3 scripts/bench_wave.py 1280 8000 > $O/wave_unet.txt 2>&1
+timeout -k 10 300 python3 scripts/bench_wave.py 64 160000 >> $O/wave_unet.txt 2>&1
+timeout -k 10 300 python3 scripts/bench_wave.py 256 8000 >> $O/wave_unet.txt 2>&1
 bash scripts/profile_augment.sh > $O/profile_augment.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 S="$R/scripts/bench_synth.py 512 512"
@@ -26,4 +29,5 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/spmc/f -o p -- python3 $S > $O/spmc_f.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/spmc/w -o p -- python3 $S > $O/spmc_w.log 2>&1
 python3 $R/scripts/pmc_traffic.py $O/spmc $O/synth_hbm_traffic_per_kernel.json > $O/synth_hbm_traffic.txt
+timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wkt -o p -- python3 $R/scripts/bench_wave.py 256 8000 > $O/wkt.log 2>&1
 cat $O/synth_1024.txt
