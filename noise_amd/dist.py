@@ -49,6 +49,26 @@ def make_grad_all_reduce(group=None, single_rank=False):
     return all_reduce
 
 
+def make_grad_mean(group=None, single_rank=False):
+    """Returns f(list of gradient tensors) that replaces every tensor by its mean over ranks through ONE all-reduce of a
+    flat copy (the gradients of the shape-generic training step are separate tensors, not views of one buffer), or None
+    when there is nothing to exchange.  Assign it to `model.grad_sync`."""
+    all_reduce = make_grad_all_reduce(group, single_rank)
+    if all_reduce is None:
+        return None
+
+    def grad_mean(grads):
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        scale = all_reduce(flat)
+        flat.mul_(scale)
+        o = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[o:o + n].view(g.shape))
+            o += n
+    return grad_mean
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced [lo, hi) share of n_items for this rank (no data-path collective needed)."""
     base, rem = divmod(n_items, world)

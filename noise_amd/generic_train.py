@@ -414,7 +414,9 @@ class StepFn(torch.autograd.Function):
         losses, grads = shared_step(model, noisy, clean)
         missing = [n for n, p in model.named_parameters() if p not in grads]
         assert not missing, f"no gradient for {missing}"
-        ctx.grads = [grads[p].reshape(p.shape) for p in params]
+        ctx.grads = [grads[p].reshape(p.shape).contiguous() for p in params]
+        if getattr(model, "grad_sync", None) is not None:     # data parallel: mean over ranks (dist.make_grad_mean)
+            model.grad_sync(ctx.grads)
         all4 = losses.clone()
         ctx.mark_non_differentiable(all4)
         return losses[0].clone(), all4

@@ -214,6 +214,7 @@ class VADMobileNetV2(_LightningModule):
         self.untuned = ", ".join(dict.fromkeys(why)) or None
         self.attn_dropout = 0.1        # ScaledDotProductAttention's own default (train/models.py:22), train mode only
         self.attn_keep_masks = None    # optional explicit keep masks, one (B, heads, n, n) uint8 tensor per encoder layer
+        self.grad_sync = None          # generic training step: f(list of gradients) averaging them over ranks (dist.make_grad_mean)
         hidden = self.layer_config[-1][1]
         self.n_head = nhead
         self.d_k = hidden // nhead

@@ -26,6 +26,10 @@ def _worker(rank, world, port, out):
     flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
     scale = ar(flat)
     mean = flat * scale
+    gm = ndist.make_grad_mean()
+    gs = [torch.full((3, 2), float(rank + 1)), torch.arange(4, dtype=torch.float32) * (rank + 1)]
+    gm(gs)
+    assert torch.equal(gs[0], torch.full((3, 2), 1.5)) and torch.equal(gs[1], torch.arange(4, dtype=torch.float32) * 1.5)
     metrics = ndist.reduce_metrics(torch.tensor([float(rank), 2.0, 4.0 * rank, 1.0]))
     lo, hi = ndist.shard_range(11, rank, world)
     out.put((rank, mean.tolist(), metrics.tolist(), (lo, hi)))
@@ -55,7 +59,7 @@ def test_two_rank_gradient_mean_and_sharding():
 
 def test_single_process_is_a_noop():
     from noise_amd import dist as ndist
-    assert ndist.make_grad_all_reduce() is None
+    assert ndist.make_grad_all_reduce() is None and ndist.make_grad_mean() is None
     assert ndist.shard_range(10, 0, 1) == (0, 10)
     covered = []
     for r in range(8):

@@ -281,3 +281,20 @@ def test_training_step_vs_reference_fixture(name):
     for key in G10.files:
         if key.startswith(f"{name}_buf/"):
             np.testing.assert_allclose(bufs[key.split("/", 1)[1]].cpu().numpy(), G10[key], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
+def test_grad_sync_hook_sees_every_gradient():
+    """`model.grad_sync` (dist.make_grad_mean over RCCL on a multi-GPU job) gets the step's gradients before autograd does."""
+    name = "narrow"
+    x1, clean = torch.from_numpy(G9[f"{name}_x1"]).to(DEV), torch.from_numpy(G9[f"{name}_val_clean"]).to(DEV)
+    masks = g10_masks(name, 2)
+    got = []
+    for hook in (None, lambda grads: [g.mul_(0.5) for g in grads]):
+        m = build(name, linear_gain=1.0).to(DEV).eval()
+        m(x1)
+        m.train()
+        m.attn_keep_masks = masks
+        m.grad_sync = hook
+        m.training_step((x1, clean, None), 0).backward()
+        got.append([p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(0.5 * a, b) for a, b in zip(*got))      # also: a step is reproducible run to run
