@@ -298,3 +298,33 @@ def test_grad_sync_hook_sees_every_gradient():
         m.training_step((x1, clean, None), 0).backward()
         got.append([p.grad.clone() for p in m.parameters()])
     assert all(torch.equal(0.5 * a, b) for a, b in zip(*got))      # also: a step is reproducible run to run
+
+
+def test_base_forward_on_a_tuned_configuration():
+    """`VADMobileNetV2.forward` (Base.forward: normalise, U-Net, gate, de-normalise) when the U-Net is the tuned per-layer
+    engine (spectralv2.yaml's rows, pad_value -1) rather than the generic path."""
+    from noise_amd.models import VADMobileNetV2
+    from oracle import wave_unet as owu
+    lc = [[1, 32, 1, [3, 3], [2, 2]], [1, 16, 1, [3, 3], [1, 1]], [3, 24, 1, [3, 3], [2, 2]], [3, 32, 1, [3, 3], [2, 2]],
+          [3, 64, 1, [3, 3], [2, 2]]]
+    torch.manual_seed(3)
+    m = VADMobileNetV2(6, 1, 0.0, layer_config=lc, pad_value=-1)
+    assert m.untuned is None
+    MG.perturb(m, 3)
+    x = torch.randn(2, 1, 161, 51, generator=torch.Generator().manual_seed(4)) * 0.3
+    with torch.no_grad():
+        m.eval()
+        _, v0 = owu.forward(m, owu.normalize(x)[0], False)
+        m.vad.bias.sub_(v0.mean())                       # a gate that is neither 0 nor 1
+        want = owu.full_forward(m, x, False)
+        wf, wv = owu.forward(m, owu.normalize(x)[0], False)
+    pad = (m.H_padding, m.W_padding)
+    m.H_padding = m.W_padding = 0
+    m.searching = m.found = False
+    g = m.to(DEV)
+    from noise_amd.generic import normalize
+    gf, gv = g._forward(normalize(x.to(DEV))[0])
+    assert (g.H_padding, g.W_padding) == pad
+    close(gf, wf.numpy(), 2e-4, "filters")
+    close(gv, wv.numpy(), 1e-5, "vad")
+    close(g(x.to(DEV)), want.numpy(), 5e-3, "forward")
