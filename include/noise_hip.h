@@ -429,9 +429,13 @@ int noise_tok_vad(const float* x, int ld, long tokens_per_clip, const float* w, 
  * of a convolution's raw output come in the lazy form (dz, y_out, coef3) that noise_bn_bwd leaves; coef3 == NULL: dz ---- */
 /* out[c] = sum over rows of slab [rows][cols] (the fixed-order fold behind every reduction below) */
 int noise_gen_slab_reduce(const float* slab, int rows, long cols, float* out, void* stream);
-/* 1x1 layer (models.py:371-381, :395-396): g_in [npix][Cin] = dy [npix][Cout] x Wt^T, Wt = weight transposed [Cin][ldw] */
+/* 1x1 layer (models.py:371-381, :395-396): g_in [npix][Cin] = dy [npix][Cout] x Wt^T, Wt = weight transposed [Cin][ldw].
+ * Optional epilogue (epi_y != NULL: the layer's input is act(BatchNorm(epi_y)), epi_coef its [scale|shift|mean|invstd|
+ * mean_lo]): g_in is masked by that ReLU6 (epi_relu6) and slab gets *rows rows of [sum g | sum g*xhat] (2 Cin floats, at
+ * most noise_ofa_max_rows() rows) for noise_bn_bwd_finalize */
 int noise_gen_pw_dgrad(const float* dz, const float* y_out, const float* coef3, const float* Wt, int ldw, float* g_in,
-                       long npix, int Cout, int Cin, void* stream);
+                       const float* epi_y, const float* epi_coef, int epi_relu6, float* slab, int* rows, long npix, int Cout,
+                       int Cin, void* stream);
 /* dW [Cout][Cin] = sum_p dy[p] (x) a[p], a = the layer's lazily normalised input; slab: noise_gen_pw_wgrad_rows() x Cout*Cin */
 int noise_gen_pw_wgrad_rows(long npix, int Cout, int Cin);
 int noise_gen_pw_wgrad(const float* dz, const float* y_out, const float* coef3, const float* a_y, const float* a_coef,

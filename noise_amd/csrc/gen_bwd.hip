@@ -8,14 +8,25 @@
 
 namespace {
 
-// out[c] = sum_r slab[r][c]
+// out[c] = sum_r slab[r][c].  A workgroup folds 64 columns: four row lanes take every fourth row each and are combined in a
+// fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void gen_slab_reduce_kernel(const float* __restrict__ slab, int rows, long cols,
                                                               float* __restrict__ out) {
-  const long c = (long)blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += slab[(size_t)r * cols + c];
-  out[c] = s;
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long c = (long)blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int r = rl;
+    for (; r + 4 < rows; r += 8) {   // two independent chains per thread
+      s0 += slab[(size_t)r * cols + c];
+      s1 += slab[(size_t)(r + 4) * cols + c];
+    }
+    if (r < rows) s0 += slab[(size_t)r * cols + c];
+  }
+  part[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && c < cols) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 // ---- weight gradient of a 1x1 layer: dW[co][ci] = sum_p dy[p][co] a[p][ci] ------------------------------------------------
@@ -455,7 +466,7 @@ inline int pow2_lanes(int C) {
 
 NOISE_EXPORT int noise_gen_slab_reduce(const float* slab, int rows, long cols, float* out, void* stream) {
   NOISE_REQUIRE(slab && out && rows > 0 && cols > 0, "noise_gen_slab_reduce: bad argument");
-  hipLaunchKernelGGL(gen_slab_reduce_kernel, dim3(noise_cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, slab, rows, cols, out);
+  hipLaunchKernelGGL(gen_slab_reduce_kernel, dim3(noise_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, slab, rows, cols, out);
   NOISE_CHECK_LAUNCH("noise_gen_slab_reduce");
   return 0;
 }
@@ -463,7 +474,8 @@ NOISE_EXPORT int noise_gen_slab_reduce(const float* slab, int rows, long cols, f
 // rows of the partial slab noise_gen_pw_wgrad writes for npix pixels (each Cout*Cin floats)
 NOISE_EXPORT int noise_gen_pw_wgrad_rows(long npix, int Cout, int Cin) {
   const long ntiles = (npix + 63) / 64;
-  long rows = 2048 / ((long)noise_cdiv(Cout, 64) * noise_cdiv(Cin, 64));
+  // three workgroups per CU over the whole grid: more rows only lengthen the fold
+  long rows = noise_cdiv(768, (long)noise_cdiv(Cout, 64) * noise_cdiv(Cin, 64));
   const long cap = (64L << 20) / ((long)Cout * Cin * 4);   // at most 64 MiB of partials
   if (rows > cap) rows = cap;
   if (rows > ntiles) rows = ntiles;

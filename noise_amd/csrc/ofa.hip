@@ -251,7 +251,8 @@ constexpr int PWG_KC = 32, PWG_PITCH = 36;
 // slab == nullptr skips the statistics.
 template <int NT, bool GRAD>
 __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad, const float* __restrict__ W,
-                                                     float* __restrict__ out, float* __restrict__ slab, PwGDims d) {
+                                                     float* __restrict__ out, float* __restrict__ slab, PwGDims d,
+                                                     LazySrc epi) {
   __shared__ float As[64 * PWG_PITCH];
   __shared__ float Ws[NT * 16 * PWG_PITCH];
   __shared__ float red[4 * 2 * NT * 16];
@@ -345,11 +346,28 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
         const int n = n0 + 16 * m + 4 * q;
-        const float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         if (pix < d.npix && n < N) {
-          st4(out + (size_t)pix * N + n, o);
-          s1[m] = s1[m] + o;
-          s2[m] = fma4(o, o, s2[m]);
+          if (GRAD && epi.y != nullptr) {
+            // backward epilogue: `out` is the gradient of the activated output of the BatchNorm (+ReLU6) whose raw
+            // input is epi.y; mask it and leave that BatchNorm's two backward sums (sum g, sum g * xhat) in the slab
+            const float4 yraw = ld4(epi.y + (size_t)pix * N + n);
+            if (epi.relu6) {
+              const float4 v = fma4(yraw, ld4(epi.coef + n), ld4(epi.coef + N + n));
+              o.x = (v.x > 0.f && v.x < 6.f) ? o.x : 0.f;
+              o.y = (v.y > 0.f && v.y < 6.f) ? o.y : 0.f;
+              o.z = (v.z > 0.f && v.z < 6.f) ? o.z : 0.f;
+              o.w = (v.w > 0.f && v.w < 6.f) ? o.w : 0.f;
+            }
+            const float4 xh = sub4(sub4(yraw, ld4(epi.coef + 2 * N + n)), ld4(epi.coef + 4 * N + n)) * ld4(epi.coef + 3 * N + n);
+            st4(out + (size_t)pix * N + n, o);
+            s1[m] = s1[m] + o;
+            s2[m] = fma4(o, xh, s2[m]);
+          } else {
+            st4(out + (size_t)pix * N + n, o);
+            s1[m] = s1[m] + o;
+            s2[m] = fma4(o, o, s2[m]);
+          }
         }
       }
     }
@@ -575,9 +593,9 @@ NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src
   if (gy > want) gy = want;
   const LazyGrad none{nullptr, nullptr, nullptr};
   if (wide)
-    hipLaunchKernelGGL((ofa_pw_kernel<8, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d);
+    hipLaunchKernelGGL((ofa_pw_kernel<8, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d, src);
   else
-    hipLaunchKernelGGL((ofa_pw_kernel<4, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d);
+    hipLaunchKernelGGL((ofa_pw_kernel<4, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d, src);
   *rows = gy;
   NOISE_CHECK_LAUNCH("noise_ofa_pw");
   return 0;
@@ -585,13 +603,19 @@ NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src
 
 // Input gradient of a 1x1 layer: g_in [npix][Cin] = dy [npix][Cout] x Wt[:Cin, :Cout]^T with Wt = the layer's weight
 // transposed (row stride ldw) and dy the lazily evaluated gradient (dz, y_out, coef3); coef3 == NULL: dy = dz.
+// Optional epilogue (epi_y != NULL): the layer's input is act(BatchNorm(epi_y)) with coefficients epi_coef
+// ([scale|shift|mean|invstd|mean_lo], Cin each); g_in is then masked by that ReLU6 (epi_relu6) and slab receives *rows rows
+// of [sum g | sum g * xhat] (2 Cin floats) for noise_bn_bwd_finalize.  slab: noise_ofa_max_rows() x 2 Cin floats.
 NOISE_EXPORT int noise_gen_pw_dgrad(const float* dz, const float* y_out, const float* coef3, const float* Wt, int ldw,
-                                    float* g_in, long npix, int Cout, int Cin, void* stream) {
+                                    float* g_in, const float* epi_y, const float* epi_coef, int epi_relu6, float* slab,
+                                    int* rows, long npix, int Cout, int Cin, void* stream) {
   NOISE_REQUIRE(dz && Wt && g_in && (coef3 == nullptr || y_out != nullptr), "noise_gen_pw_dgrad: null pointer");
+  NOISE_REQUIRE(epi_y == nullptr || (epi_coef && slab && rows), "noise_gen_pw_dgrad: the epilogue needs coefficients and a slab");
   NOISE_REQUIRE(npix > 0 && Cout >= 4 && Cout % 4 == 0 && Cin >= 4 && Cin % 4 == 0 && ldw >= Cout && ldw % 4 == 0,
                 "noise_gen_pw_dgrad: widths and the weight row stride must be multiples of 4 (Cout %d, Cin %d, stride %d)", Cout,
                 Cin, ldw);
   const LazySrc none{nullptr, nullptr, 0};
+  const LazySrc epi{epi_y, epi_coef, epi_relu6};
   const LazyGrad grad{dz, y_out, coef3};
   const PwGDims d{npix, Cout, Cin, ldw};
   const long ntiles = (npix + 63) / 64;
@@ -600,10 +624,12 @@ NOISE_EXPORT int noise_gen_pw_dgrad(const float* dz, const float* y_out, const f
   int gy = pixel_rows(ntiles, 1);
   const int want = noise_cdiv(2048, gx);
   if (gy > want) gy = want;
+  float* st = epi_y ? slab : nullptr;
   if (wide)
-    hipLaunchKernelGGL((ofa_pw_kernel<8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, nullptr, d);
+    hipLaunchKernelGGL((ofa_pw_kernel<8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, st, d, epi);
   else
-    hipLaunchKernelGGL((ofa_pw_kernel<4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, nullptr, d);
+    hipLaunchKernelGGL((ofa_pw_kernel<4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, st, d, epi);
+  if (rows) *rows = gy;
   NOISE_CHECK_LAUNCH("noise_gen_pw_dgrad");
   return 0;
 }

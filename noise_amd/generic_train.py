@@ -9,6 +9,7 @@ materialised tensors (block outputs, token matrices) are plain tensors, summed w
 (dz, y, coef3) that `noise_bn_bwd` leaves and the convolution backward kernels evaluate on load.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -20,7 +21,7 @@ from .generic import GenericForward, _taps3x3, finish, normalize
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _lib.register({
     "noise_gen_slab_reduce": [_P, _I, _L, _P, _P],
-    "noise_gen_pw_dgrad": [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P],
+    "noise_gen_pw_dgrad": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_gen_pw_wgrad": [_P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
     "noise_gen_colsum": [_P, _I, _L, _I, _P, _P, _P],
     "noise_gen_relu_bwd": [_P, _P, _P, _L, _P],
@@ -39,14 +40,19 @@ _lib.lib.noise_gen_last_bwd_rows.argtypes = []
 
 
 # ---------------------------------------------------------------------------------------------- thin wrappers
-def pw_dgrad(grad, w, npix, Cout, Cin):
-    """g_in [npix][Cin] of a 1x1 layer with weight w (Cout, Cin[, 1, 1]) against the lazy gradient `grad`."""
+def pw_dgrad(grad, w, npix, Cout, Cin, epi=None, slab=None):
+    """g_in [npix][Cin] of a 1x1 layer with weight w (Cout, Cin[, 1, 1]) against the lazy gradient `grad`.  With
+    `epi = (y, coef, relu6)` of the BatchNorm (+ReLU6) that produced the layer's input, g_in comes back masked and
+    (g_in, rows) is returned: `slab` then holds `rows` rows of that BatchNorm's backward sums (2 Cin floats each)."""
     dz, y, coef3 = grad
     wt = w.reshape(Cout, Cin).t().contiguous()
     g = torch.empty(npix, Cin, device=dz.device, dtype=torch.float32)
-    _lib.call("noise_gen_pw_dgrad", ptr(dz), ptr(y), ptr(coef3), ptr(wt), Cout, ptr(g), npix, Cout, Cin, _lib.stream(),
-              nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin))
-    return g
+    rows = ctypes.c_int(0)
+    ey, ecoef, erelu = epi if epi is not None else (None, None, False)
+    _lib.call("noise_gen_pw_dgrad", ptr(dz), ptr(y), ptr(coef3), ptr(wt), Cout, ptr(g), ptr(ey), ptr(ecoef), int(bool(erelu)),
+              ptr(slab), ctypes.byref(rows), npix, Cout, Cin, _lib.stream(),
+              nbytes=4 * npix * (Cout * (2 if coef3 is not None else 1) + Cin * (2 if epi is not None else 1)))
+    return (g, rows.value) if epi is not None else g
 
 
 def pw_wgrad(grad, src, npix, Cout, Cin):
@@ -126,6 +132,14 @@ class GenericTrain(GenericForward):
     def take(self, t):
         return self.g.pop(id(t))[1]
 
+    def bn_finalize(self, dz, slab, rows, row_stride, y, coef, bn, npix, C):
+        """The rest of a BatchNorm backward whose masked gradient `dz` and two sums a consumer's epilogue already left."""
+        dgb = self.new(2 * C)
+        coef3 = self.new(6 * C)
+        ops.bn_bwd_finalize(slab, rows, row_stride, coef, bn.weight, dgb[:C], dgb[C:], coef3, npix, C)
+        self.grads[bn.weight], self.grads[bn.bias] = dgb[:C], dgb[C:]
+        return dz, y, coef3
+
     def bn_bwd(self, g_act, y, coef, relu6, bn, npix, C):
         """BatchNorm (+ReLU6) backward: gradient of the activated output -> lazy gradient of the raw convolution output."""
         dz = self.new(npix, C)
@@ -171,18 +185,25 @@ class GenericTrain(GenericForward):
                 self.acc(x, G)
             g3 = self.bn_bwd(G, y3, coef3, False, bn3, npo, N)
             self.grads[conv3.weight] = pw_wgrad(g3, (y2, coef2, True), npo, N, C).view_as(conv3.weight)
-            ga2 = pw_dgrad(g3, conv3.weight, npo, N, C)
-            g2 = self.bn_bwd(ga2, y2, coef2, True, dwl[1], npo, C)
+            # every backward kernel finishes the BatchNorm (+ReLU6) backward of the layer that produced its input: it
+            # masks its output and leaves the two per-channel sums, so those BatchNorms cost no pass of their own
+            dz2, rows = pw_dgrad(g3, conv3.weight, npo, N, C, epi=(y2, coef2, True), slab=self.slab)
+            g2 = self.bn_finalize(dz2, self.slab, rows, 2 * C, y2, coef2, dwl[1], npo, C)
             conv2 = dwl[0]
             tr = isinstance(conv2, nn.ConvTranspose2d)
             s = self._stride(conv2, Hi)
             w9 = _taps3x3(conv2, False).contiguous()
             ga1, dw9 = self.new(B, Hi, Wi, C), self.new(C, 3, 3)
-            ops.dw3x3_bwd(g2, src, None, w9, ga1, dw9, self.scratch, tr, B, Hi, Wi, C, (s, s))
+            # a one-row kernel couples no rows, so a batch of one-row tensors is one image of B rows to it (the other two
+            # rows of the embedded 3x3 kernel are zero): the stride-1 column walkers then walk B rows instead of one
+            rows_as_image = Hi == 1 and s == 1 and conv2.kernel_size[0] == 1 and os.environ.get("NOISE_GEN_ROWS") != "0"
+            Bk, Hk = (1, B) if rows_as_image else (B, Hi)
+            epi = (exp[3], True) if exp is not None else None
+            rows = ops.dw3x3_bwd(g2, src, None, w9, ga1, dw9, self.scratch, tr, Bk, Hk, Wi, C, (s, s), None, epi)
             self.grads[conv2.weight] = self._dw_grad(conv2, dw9)
             if exp is not None:
                 conv1, bn1, y1, coef1 = exp
-                g1 = self.bn_bwd(ga1, y1, coef1, True, bn1, npi, C)
+                g1 = self.bn_finalize(ga1, self.scratch[9 * C:], rows, 11 * C, y1, coef1, bn1, npi, C)
                 self.grads[conv1.weight] = pw_wgrad(g1, (x, None, False), npi, C, Cin).view_as(conv1.weight)
                 self.acc(x, pw_dgrad(g1, conv1.weight, npi, C, Cin), own=True)
             else:

@@ -155,3 +155,27 @@ def test_last_convT_bwd(B, Hi, Wi, C):
     F.conv_transpose2d(a64, w64, None, 2, 1).backward(dout.double().view(B, 1, Hy, Wy))
     assert rel(gin, a64.grad.permute(0, 2, 3, 1)) < 1e-5
     assert rel(dw, w64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("npix,Cout,Cin,relu6", [(1000, 16, 96, True), (4100, 128, 576, True), (333, 20, 12, False)])
+def test_pw_dgrad_epilogue(npix, Cout, Cin, relu6):
+    """Input gradient masked by the producer's ReLU6 + that BatchNorm's two backward sums, as the epilogue leaves them."""
+    from noise_amd import _lib, generic_train as gt
+    g = torch.Generator().manual_seed(npix + 1)
+    grad, dy = lazy_grad(g, npix, Cout, True)
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(DEV)
+    ey = torch.randn(npix, Cin, generator=g).to(DEV)
+    scale, shift = 1 + 0.2 * torch.randn(Cin, generator=g), 2 + torch.randn(Cin, generator=g)
+    mean, istd = 0.1 * torch.randn(Cin, generator=g), 0.5 + torch.rand(Cin, generator=g)
+    coef = torch.cat([scale, shift, mean, istd, 1e-8 * torch.randn(Cin, generator=g)]).to(DEV)
+    slab = torch.empty(_lib.lib.noise_ofa_max_rows() * 2 * Cin, device=DEV)
+    got, rows = gt.pw_dgrad(grad, w, npix, Cout, Cin, epi=(ey, coef, relu6), slab=slab)
+    want = dy @ w.double()
+    c = coef.double()
+    if relu6:
+        v = ey.double() * c[:Cin] + c[Cin:2 * Cin]
+        want = want * ((v > 0) & (v < 6))
+    assert rel(got, want) < 1e-5
+    xh = ((ey.double() - c[2 * Cin:3 * Cin]) - c[4 * Cin:]) * c[3 * Cin:4 * Cin]
+    sums = slab[:rows * 2 * Cin].view(rows, 2 * Cin).double().sum(0)
+    assert rel(sums[:Cin], want.sum(0)) < 2e-5 and rel(sums[Cin:], (want * xh).sum(0)) < 2e-5
