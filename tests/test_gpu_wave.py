@@ -328,3 +328,17 @@ def test_base_forward_on_a_tuned_configuration():
     close(gf, wf.numpy(), 2e-4, "filters")
     close(gv, wv.numpy(), 1e-5, "vad")
     close(g(x.to(DEV)), want.numpy(), 5e-3, "forward")
+
+
+def test_first_call_can_be_a_training_step():
+    """A fresh model whose first call is `training_step`: the padding search runs inside it (whole train-mode forwards that
+    move the running statistics, models.py:628-639), then the step itself."""
+    m = build("narrow", linear_gain=1.0).to(DEV).train()
+    m.attn_dropout = 0.0
+    x1, clean = torch.from_numpy(G9["narrow_x1"]).to(DEV), torch.from_numpy(G9["narrow_val_clean"]).to(DEV)
+    loss = m.training_step((x1, clean, None), 0)
+    loss.backward()
+    assert m.found and m.W_padding >= 1
+    nbt = int(dict(m.named_buffers())["encoder.0.1.num_batches_tracked"])
+    assert nbt == m.W_padding + m.H_padding + 2          # search forwards (1 + one per padding step) + the step
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
