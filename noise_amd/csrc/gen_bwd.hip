@@ -30,20 +30,36 @@ __global__ __launch_bounds__(256) void gen_slab_reduce_kernel(const float* __res
 }
 
 // ---- weight gradient of a 1x1 layer: dW[co][ci] = sum_p dy[p][co] a[p][ci] ------------------------------------------------
-// A workgroup owns a 64 x 64 block of dW (blockIdx.x, blockIdx.y) and walks 64-pixel tiles from blockIdx.z: both
-// operands are staged in LDS with their lazy transforms applied, wave w multiplies output-channel tile w with the four
-// input-channel tiles (v_mfma_f32_16x16x4_f32, k = pixels).  Partial blocks go to slab[blockIdx.z][Cout][Cin].
-constexpr int WGR_P = 68;
+// A workgroup owns a block of dW and walks pixel tiles from blockIdx.z: both operands are staged in LDS with their lazy
+// transforms applied and multiplied by v_mfma_f32_16x16x4_f32 with k = pixels.  One operand (the "wave side", 64
+// channels per workgroup, blockIdx.x) gives every wave one 16-channel tile; the other (the "loop side", 16 CT channels,
+// blockIdx.y) is walked by every wave, so a staged wave-side value feeds CT matrix products.  SWAP = false: the wave side
+// is dy (output channels), the loop side the layer input; SWAP = true the other way round, which is how a layer with few
+// output channels keeps all four waves busy.  Wide loop sides (CT >= 8) take 32-pixel tiles, the others 64.
+// Row pitches are 16 (mod 64) floats: the four pixel rows a matrix product reads fall into four disjoint bank groups.
+// Partial blocks go to slab[blockIdx.z][Cout][Cin].
+constexpr int WGR_P = 80;
 
+template <int CT, bool SWAP>
 __global__ __launch_bounds__(256) void gen_pw_wgrad_kernel(LazyGrad G, LazySrc A, float* __restrict__ slab, long npix, int N,
                                                            int K) {
-  __shared__ float dys[64 * WGR_P];
-  __shared__ float as[64 * WGR_P];
+  constexpr int PT = CT >= 8 ? 32 : 64;                 // pixels per tile
+  constexpr int YP = CT == 1 ? 16 : 16 * CT + 16;       // loop-side row pitch
+  constexpr int YQ = 4 * CT, YROWS = 256 / YQ;          // loop-side channel quads; rows one pass of the workgroup covers
+  constexpr int YI = PT / YROWS, XI = PT / 16;          // float4 a thread stages per tile, loop side / wave side
+  __shared__ float xs[PT * WGR_P];
+  __shared__ float ys[PT * YP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, q = lane >> 4;
-  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
-  const int cq = tid & 15, r0 = tid >> 4;
-  const int co = co0 + 4 * cq, ci = ci0 + 4 * cq;
+  const int cx0 = blockIdx.x * 64, cy0 = blockIdx.y * 16 * CT;
+  const int xq = tid & 15, xr0 = tid >> 4, yq = tid % YQ, yr0 = tid / YQ;
+  // the gradient operand and the input operand, whichever side each is on
+  constexpr int GI = SWAP ? YI : XI, GSTEP = SWAP ? YROWS : 16, GP = SWAP ? YP : WGR_P;
+  constexpr int AI = SWAP ? XI : YI, ASTEP = SWAP ? 16 : YROWS, AP = SWAP ? WGR_P : YP;
+  float* const gbuf = SWAP ? ys : xs;
+  float* const abuf = SWAP ? xs : ys;
+  const int gq = SWAP ? yq : xq, gr0 = SWAP ? yr0 : xr0, aq = SWAP ? xq : yq, ar0 = SWAP ? xr0 : yr0;
+  const int co = (SWAP ? cy0 : cx0) + 4 * gq, ci = (SWAP ? cx0 : cy0) + 4 * aq;
   const bool von = co < N, vok = ci < K;
   const int coc = von ? co : 0, cic = vok ? ci : 0;
   const bool affine = G.coef3 != nullptr;
@@ -58,46 +74,109 @@ __global__ __launch_bounds__(256) void gen_pw_wgrad_kernel(LazyGrad G, LazySrc A
   }
   const float4 asc = A.coef ? ld4(A.coef + cic) : f4(1.f), ash = A.coef ? ld4(A.coef + K + cic) : f4(0.f);
   const float alo = A.relu6 ? 0.f : -INFINITY, ahi = A.relu6 ? 6.f : INFINITY;
-  f32x4 acc[4];
+  // a wave whose 16 wave-side channels do not exist has nothing to multiply (it still stages and waits with the others)
+  const bool wave_on = cx0 + 16 * wave < (SWAP ? K : N);
+  f32x4 acc[CT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long ntiles = (npix + 63) / 64;
-  for (long tile = blockIdx.z; tile < ntiles; tile += gridDim.z) {
-    float4 rz[4], ry[4], ra[4];
+  for (int j = 0; j < CT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (npix + PT - 1) / PT;
+  float4 rz[GI], ry[GI], ra[AI];
+  auto fetch = [&](long tile) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long pix = tile * 64 + r0 + 16 * i;
+    for (int i = 0; i < GI; ++i) {
+      const long pix = tile * PT + gr0 + GSTEP * i;
       const size_t pc = (size_t)(pix < npix ? pix : npix - 1);
       rz[i] = ld4(G.dz + pc * N + coc);
       ry[i] = affine ? ld4(G.y + pc * N + coc) : f4(0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const long pix = tile * PT + ar0 + ASTEP * i;
+      const size_t pc = (size_t)(pix < npix ? pix : npix - 1);
       ra[i] = ld4(A.y + pc * K + cic);
     }
+  };
+  if ((long)blockIdx.z < ntiles) fetch(blockIdx.z);
+  for (long tile = blockIdx.z; tile < ntiles; tile += gridDim.z) {
     __syncthreads();   // the previous tile's products have read the staged operands
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool in = tile * 64 + r0 + 16 * i < npix;
+    for (int i = 0; i < GI; ++i) {
+      const bool in = tile * PT + gr0 + GSTEP * i < npix;
       const float4 dy = affine ? fma4(a2, sub4(sub4(ry[i], mh), ml), gs * sub4(sub4(rz[i], k1h), k1l)) : rz[i];
-      st4(dys + (r0 + 16 * i) * WGR_P + 4 * cq, (in && von) ? dy : f4(0.f));
-      st4(as + (r0 + 16 * i) * WGR_P + 4 * cq, (in && vok) ? clamp4(fma4(ra[i], asc, ash), alo, ahi) : f4(0.f));
+      st4(gbuf + (gr0 + GSTEP * i) * GP + 4 * gq, (in && von) ? dy : f4(0.f));
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const bool in = tile * PT + ar0 + ASTEP * i < npix;
+      st4(abuf + (ar0 + ASTEP * i) * AP + 4 * aq, (in && vok) ? clamp4(fma4(ra[i], asc, ash), alo, ahi) : f4(0.f));
     }
     __syncthreads();
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const int pp = 4 * s + q;
-      const float dv = dys[pp * WGR_P + 16 * wave + p];
+    // the next tile's memory round trip runs under this tile's matrix products
+    if (tile + gridDim.z < ntiles) fetch(tile + gridDim.z);
+    if (wave_on) {
+#pragma unroll 2
+      for (int s = 0; s < PT / 4; ++s) {
+        const int pp = 4 * s + q;
+        const float xv = xs[pp * WGR_P + 16 * wave + p];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, as[pp * WGR_P + 16 * j + p], acc[j], 0, 0, 0);
+        for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, ys[pp * YP + 16 * j + p], acc[j], 0, 0, 0);
+      }
     }
   }
   float* blk = slab + (size_t)blockIdx.z * N * K;
+  if (!wave_on) return;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < CT; ++j) {
+    if (SWAP) {   // acc[j][e]: input channel cx0 + 16 wave + 4 q + e, output channel cy0 + 16 j + p
+      const int o = cy0 + 16 * j + p, i = cx0 + 16 * wave + 4 * q;
+      if (o < N && i < K) st4(blk + (size_t)o * K + i, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int o = co0 + 16 * wave + 4 * q + e, i = ci0 + 16 * j + p;
-      if (o < N && i < K) blk[(size_t)o * K + i] = acc[j][e];
+      for (int e = 0; e < 4; ++e) {
+        const int o = cx0 + 16 * wave + 4 * q + e, i = cy0 + 16 * j + p;
+        if (o < N && i < K) blk[(size_t)o * K + i] = acc[j][e];
+      }
     }
   }
+}
+
+// Blocking of the weight gradient for a Cout x Cin layer: which operand the waves split, and how many 16-channel tiles
+// of the other one a workgroup walks.  Every (side, tile count) pair is priced from the matrix-core time of its padded
+// block grid (tm) and the time to stage each operand once per block of the other side (tb, mostly L2 hits: the blocks
+// of one pixel range run together), and the cheapest is taken.  The two overlap fully at four waves per SIMD (one or two
+// tiles) and for about a fifth at three (four or eight tiles); sixteen tiles leave two waves per SIMD and no overlap.
+// Constants fitted to a sweep of all ten blockings over the layer shapes of the waveform network
+// (scripts/dbg/wgrad_sweep.py).
+struct WgradPlan {
+  bool swap;
+  int ct, pt, nx, ny;
+};
+inline WgradPlan wgrad_plan(int Cout, int Cin) {
+  WgradPlan best{false, 4, 64, noise_cdiv(Cout, 64), noise_cdiv(Cin, 64)};
+  double best_t = 1e30;
+  static const char* force = getenv("NOISE_WGRAD_PLAN");   // diagnostic: "<swap><ct>", e.g. "08" or "116"
+  if (force && force[0]) {
+    const bool sw = force[0] == '1';
+    const int ct = atoi(force + 1);
+    const int Cw = sw ? Cin : Cout, Cl = sw ? Cout : Cin;
+    return WgradPlan{sw, ct, ct >= 8 ? 32 : 64, noise_cdiv(Cw, 64), noise_cdiv(Cl, 16 * ct)};
+  }
+  for (int sw = 0; sw < 2; ++sw) {
+    const int Cw = sw ? Cin : Cout, Cl = sw ? Cout : Cin;
+    const double gw = sw ? 1.0 : 2.0, gl = sw ? 2.0 : 1.0;   // the gradient operand is two tensors (dz and y)
+    for (int ct = 1; ct <= 16; ct *= 2) {
+      const int nx = noise_cdiv(Cw, 64), ny = noise_cdiv(Cl, 16 * ct);
+      const double flops = 2.0 * nx * 64.0 * ny * 16.0 * ct, bytes = 4.0 * (ny * Cw * gw + nx * Cl * gl);
+      const double tm = flops / 124e12 * (ct == 16 ? 1.15 : 1.0), tb = bytes / 6.6e12;
+      const double ov = ct <= 2 ? 0.0 : (ct <= 8 ? 0.8 : 1.0);
+      const double t = (tm > tb ? tm : tb) + ov * (tm < tb ? tm : tb) + 1e-3 * tb;
+      if (t < best_t) {
+        best_t = t;
+        best = WgradPlan{sw != 0, ct, ct >= 8 ? 32 : 64, nx, ny};
+      }
+    }
+  }
+  return best;
 }
 
 // ---- column sums of a row-major matrix (bias gradients): slab[blockIdx.x][N] ----------------------------------------------
@@ -233,6 +312,23 @@ __global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict
 // thread owns a key): dv_j = sum_i p_ij keep_ij keep_scale dO_i, dk_j = sum_i ds_ij q_i / T.  No atomics.
 constexpr int ATB_KB = 128;
 
+// 16 consecutive keep bytes of a query's row (any alignment) as four words; only the first `count` are read from memory
+// (byte-sized loads along a thread's own row touch a different cache line in every lane for every key).
+__device__ __forceinline__ void keep_bytes16(const unsigned char* p, int count, unsigned (&w)[4]) {
+  if (count >= 16) {
+    __builtin_memcpy(w, p, 16);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned v = 0;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        if (4 * e + bb < count) v |= (unsigned)p[4 * e + bb] << (8 * bb);
+      w[e] = v;
+    }
+  }
+}
+
 template <int DKP>
 __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, int ld,
@@ -243,7 +339,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __rest
   __shared__ float Ks[ATB_KB * DKP];
   __shared__ float Vs[ATB_KB * DKP];
   const int h = blockIdx.y, b = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   const size_t row0 = (size_t)b * n, ic = live ? i : 0;
   float qr[DKP], gr[DKP], acc[DKP];
@@ -262,7 +358,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __rest
     const float rl = pass ? 1.f / l : 0.f;
     for (int j0 = 0; j0 < n; j0 += ATB_KB) {
       __syncthreads();
-      for (int e = threadIdx.x; e < ATB_KB * DKP; e += 256) {
+      for (int e = threadIdx.x; e < ATB_KB * DKP; e += blockDim.x) {
         const int j = e / DKP, d = e - j * DKP;
         const bool in = j0 + j < n && d < dk;
         Ks[e] = in ? k[(row0 + j0 + j) * ld + h * dk + d] : 0.f;
@@ -270,25 +366,43 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __rest
       }
       __syncthreads();
       const int jn = n - j0 < ATB_KB ? n - j0 : ATB_KB;
-      for (int j = 0; j < jn; ++j) {
-        float s = 0.f;
+      if (pass == 0) {
+        for (int j = 0; j < jn; ++j) {
+          float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
-        if (pass == 0) {
+          for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
           if (s > m) {
             l *= expf(m - s);
             m = s;
           }
           l += expf(s - m);
-        } else {
-          const float pj = expf(s - m) * rl;
-          float dp = 0.f;
+        }
+      } else {
+        for (int jb = 0; jb < jn; jb += 16) {
+          const int kn = jn - jb < 16 ? jn - jb : 16;
+          unsigned kw[4];
+          if (kp) keep_bytes16(kp + j0 + jb, kn, kw);
+#pragma unroll 1
+          for (int wi = 0; wi < 4; ++wi) {
+            const unsigned w = wi == 0 ? kw[0] : (wi == 1 ? kw[1] : (wi == 2 ? kw[2] : kw[3]));
 #pragma unroll
-          for (int d = 0; d < DKP; ++d) dp = fmaf(gr[d], Vs[j * DKP + d], dp);
-          if (kp) dp = kp[j0 + j] ? dp * keep_scale : 0.f;
-          const float ds = pj * (dp - Di);
+          for (int jj = 0; jj < 4; ++jj) {
+            if (4 * wi + jj < kn) {   // the same for every lane
+              const int j = jb + 4 * wi + jj;
+              float s = 0.f;
 #pragma unroll
-          for (int d = 0; d < DKP; ++d) acc[d] = fmaf(ds, Ks[j * DKP + d], acc[d]);
+              for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
+              const float pj = expf(s - m) * rl;
+              float dp = 0.f;
+#pragma unroll
+              for (int d = 0; d < DKP; ++d) dp = fmaf(gr[d], Vs[j * DKP + d], dp);
+              if (kp) dp = ((w >> (8 * jj)) & 0xffu) ? dp * keep_scale : 0.f;
+              const float ds = pj * (dp - Di);
+#pragma unroll
+              for (int d = 0; d < DKP; ++d) acc[d] = fmaf(ds, Ks[j * DKP + d], acc[d]);
+            }
+          }
+          }
         }
       }
     }
@@ -315,7 +429,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kv_kernel(const float* __res
   __shared__ float Gs[QB * DKP];
   __shared__ float St[QB * 3];
   const int h = blockIdx.y, b = blockIdx.z;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = j < n;
   const size_t row0 = (size_t)b * n, jc = live ? j : 0;
   float kr[DKP], vr[DKP], ak[DKP], av[DKP];
@@ -329,35 +443,48 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kv_kernel(const float* __res
   const unsigned char* kp = keep ? keep + ((size_t)b * H + h) * n * n + jc : nullptr;
   for (int i0 = 0; i0 < n; i0 += QB) {
     __syncthreads();
-    for (int e = threadIdx.x; e < QB * DKP; e += 256) {
+    for (int e = threadIdx.x; e < QB * DKP; e += blockDim.x) {
       const int i = e / DKP, d = e - i * DKP;
       const bool in = i0 + i < n && d < dk;
       Qs[e] = in ? q[(row0 + i0 + i) * ld + h * dk + d] * inv_temp : 0.f;
       Gs[e] = in ? go[(row0 + i0 + i) * ldo + h * dk + d] : 0.f;
     }
-    for (int e = threadIdx.x; e < QB * 3; e += 256)
+    for (int e = threadIdx.x; e < QB * 3; e += blockDim.x)
       St[e] = i0 + e / 3 < n ? stats[(((size_t)b * H + h) * n + i0) * 3 + e] : 0.f;
     __syncthreads();
     const int in_ = n - i0 < QB ? n - i0 : QB;
-    for (int i = 0; i < in_; ++i) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < DKP; ++d) {
-        s = fmaf(Qs[i * DKP + d], kr[d], s);
-        dp = fmaf(Gs[i * DKP + d], vr[d], dp);
-      }
-      const float pj = expf(s - St[3 * i]) * St[3 * i + 1];
-      float pm = pj;
+    for (int ib = 0; ib < in_; ib += 4) {
+      const int kn = in_ - ib < 4 ? in_ - ib : 4;
+      // the keep bytes of 4 queries are requested together (a column of the mask: consecutive lanes, consecutive bytes)
+      unsigned char kb[4];
       if (kp) {
-        const bool kept = kp[(size_t)(i0 + i) * n] != 0;
-        pm = kept ? pj * keep_scale : 0.f;
-        dp = kept ? dp * keep_scale : 0.f;
-      }
-      const float ds = pj * (dp - St[3 * i + 2]);
 #pragma unroll
-      for (int d = 0; d < DKP; ++d) {
-        av[d] = fmaf(pm, Gs[i * DKP + d], av[d]);
-        ak[d] = fmaf(ds, Qs[i * DKP + d], ak[d]);
+        for (int ii = 0; ii < 4; ++ii) kb[ii] = ii < kn ? kp[(size_t)(i0 + ib + ii) * n] : 0;
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        if (ii < kn) {   // the same for every lane
+          const int i = ib + ii;
+          float s = 0.f, dp = 0.f;
+#pragma unroll
+          for (int d = 0; d < DKP; ++d) {
+            s = fmaf(Qs[i * DKP + d], kr[d], s);
+            dp = fmaf(Gs[i * DKP + d], vr[d], dp);
+          }
+          const float pj = expf(s - St[3 * i]) * St[3 * i + 1];
+          float pm = pj;
+          if (kp) {
+            const bool kept = kb[ii] != 0;
+            pm = kept ? pj * keep_scale : 0.f;
+            dp = kept ? dp * keep_scale : 0.f;
+          }
+          const float ds = pj * (dp - St[3 * i + 2]);
+#pragma unroll
+          for (int d = 0; d < DKP; ++d) {
+            av[d] = fmaf(pm, Gs[i * DKP + d], av[d]);
+            ak[d] = fmaf(ds, Qs[i * DKP + d], ak[d]);
+          }
+        }
       }
     }
   }
@@ -473,9 +600,10 @@ NOISE_EXPORT int noise_gen_slab_reduce(const float* slab, int rows, long cols, f
 
 // rows of the partial slab noise_gen_pw_wgrad writes for npix pixels (each Cout*Cin floats)
 NOISE_EXPORT int noise_gen_pw_wgrad_rows(long npix, int Cout, int Cin) {
-  const long ntiles = (npix + 63) / 64;
+  const WgradPlan pl = wgrad_plan(Cout, Cin);
+  const long ntiles = (npix + pl.pt - 1) / pl.pt;
   // three workgroups per CU over the whole grid: more rows only lengthen the fold
-  long rows = noise_cdiv(768, (long)noise_cdiv(Cout, 64) * noise_cdiv(Cin, 64));
+  long rows = noise_cdiv(768, (long)pl.nx * pl.ny);
   const long cap = (64L << 20) / ((long)Cout * Cin * 4);   // at most 64 MiB of partials
   if (rows > cap) rows = cap;
   if (rows > ntiles) rows = ntiles;
@@ -489,11 +617,19 @@ NOISE_EXPORT int noise_gen_pw_wgrad(const float* dz, const float* y_out, const f
   NOISE_REQUIRE(npix > 0 && Cout >= 4 && Cout % 4 == 0 && Cin >= 4 && Cin % 4 == 0, "noise_gen_pw_wgrad: widths must be "
                 "multiples of 4 (Cout %d, Cin %d)", Cout, Cin);
   const int rows = noise_gen_pw_wgrad_rows(npix, Cout, Cin);
-  const dim3 grid(noise_cdiv(Cout, 64), noise_cdiv(Cin, 64), rows);
+  const WgradPlan pl = wgrad_plan(Cout, Cin);
+  const dim3 grid(pl.nx, pl.ny, rows);
   NOISE_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "noise_gen_pw_wgrad: layer too wide");
   const LazyGrad G{dz, y_out, coef3};
   const LazySrc A{a_y, a_coef, a_relu6};
-  hipLaunchKernelGGL(gen_pw_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, G, A, slab, npix, Cout, Cin);
+  hipStream_t st = (hipStream_t)stream;
+#define WG_CASE(T)                                                                                                      \
+  case T:                                                                                                               \
+    if (pl.swap) hipLaunchKernelGGL((gen_pw_wgrad_kernel<T, true>), grid, dim3(256), 0, st, G, A, slab, npix, Cout, Cin);  \
+    else hipLaunchKernelGGL((gen_pw_wgrad_kernel<T, false>), grid, dim3(256), 0, st, G, A, slab, npix, Cout, Cin);        \
+    break;
+  switch (pl.ct) { WG_CASE(1) WG_CASE(2) WG_CASE(4) WG_CASE(8) default: WG_CASE(16) }
+#undef WG_CASE
   NOISE_CHECK_LAUNCH("noise_gen_pw_wgrad");
   return noise_gen_slab_reduce(slab, rows, (long)Cout * Cin, dw, stream);
 }
@@ -544,14 +680,16 @@ NOISE_EXPORT int noise_gen_attn_bwd(const float* q, const float* k, const float*
   NOISE_REQUIRE(q && k && v && o && go && dq && dk_ && dv && stats, "noise_gen_attn_bwd: null pointer");
   NOISE_REQUIRE(B > 0 && n > 0 && H > 0 && dk > 0 && dk <= 64, "noise_gen_attn_bwd: head size must be in 1..64 (got %d)", dk);
   NOISE_REQUIRE(B <= 65535 && H <= 65535 && ld >= H * dk && ldo >= H * dk && temperature > 0.f, "noise_gen_attn_bwd: bad shape");
-  const dim3 grid(noise_cdiv(n, 256), H, B);
+  // short clips: workgroups of 64 or 128 queries / keys, so that few lanes are left without one
+  const int nt = n <= 64 ? 64 : (n <= 128 ? 128 : 256);
+  const dim3 grid(noise_cdiv(n, nt), H, B);
   hipStream_t st = (hipStream_t)stream;
   const float it = 1.f / temperature;
 #define ATB_CASE(P, QB)                                                                                                   \
   do {                                                                                                                    \
-    hipLaunchKernelGGL(gen_attn_bwd_q_kernel<P>, grid, dim3(256), 0, st, q, k, v, ld, keep, keep_scale, o, go, ldo, dq,    \
+    hipLaunchKernelGGL(gen_attn_bwd_q_kernel<P>, grid, dim3(nt), 0, st,  q, k, v, ld, keep, keep_scale, o, go, ldo, dq,    \
                        stats, n, H, dk, it);                                                                              \
-    hipLaunchKernelGGL((gen_attn_bwd_kv_kernel<P, QB>), grid, dim3(256), 0, st, q, k, v, ld, keep, keep_scale, go, ldo,    \
+    hipLaunchKernelGGL((gen_attn_bwd_kv_kernel<P, QB>), grid, dim3(nt), 0, st,  q, k, v, ld, keep, keep_scale, go, ldo,    \
                        stats, dk_, dv, n, H, dk, it);                                                                     \
   } while (0)
   if (dk <= 8) ATB_CASE(8, 128);

@@ -250,7 +250,7 @@ constexpr int PWG_KC = 32, PWG_PITCH = 36;
 // activation, which makes the same product the input gradient of a 1x1 layer (W = the layer's weight transposed).
 // slab == nullptr skips the statistics.
 template <int NT, bool GRAD>
-__global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad, const float* __restrict__ W,
+__global__ __launch_bounds__(256, (GRAD && NT == 8) ? 2 : (NT <= 4 && !GRAD ? 4 : 3)) void ofa_pw_kernel(LazySrc src, LazyGrad grad, const float* __restrict__ W,
                                                      float* __restrict__ out, float* __restrict__ slab, PwGDims d,
                                                      LazySrc epi) {
   __shared__ float As[64 * PWG_PITCH];
@@ -268,8 +268,10 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
   const int nchunk = (K + PWG_KC - 1) / PWG_KC;
   // staging maps: a thread moves 2 float4 of the input chunk (64 pixels x 8 channel quads) and NT/2 of the weight chunk
   const int kq = tid & 7, r0 = tid >> 3;
-  float4 ra[2], rsc, rsh, rw[NT / 2];
-  float4 rb[GRAD ? 2 : 1], rg[GRAD ? 4 : 1];   // GRAD: raw layer output and the remaining coefficient vectors
+  constexpr int RW = (NT + 1) / 2;   // weight rows a thread stages (32 rows apart)
+  float4 ra[2], rw[RW];
+  float4 rb[GRAD ? 2 : 1];   // GRAD: raw layer output
+  int kcur = 0;               // first channel of the chunk held in ra / rb (the coefficient vectors are read when it is staged)
   const bool affine = GRAD && grad.coef3 != nullptr;
   const float* const ay = GRAD ? grad.dz : src.y;
   unsigned vin = 0;   // bit i: ra[i] holds an existing element; bit 8+i: rw[i] does
@@ -286,21 +288,11 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
       if (GRAD) rb[i] = affine ? ld4(grad.y + (size_t)(in ? pix : 0) * K + kc) : f4(0.f);
       vin |= in ? (1u << i) : 0u;
     }
-    if (GRAD) {   // dy = s*((dz - k1_hi) - k1_lo) + a2*((y - mean_hi) - mean_lo)
-      rsc = affine ? ld4(grad.coef3 + kc) : f4(1.f);
-      rsh = affine ? ld4(grad.coef3 + 3 * K + kc) : f4(0.f);
-      rg[0] = affine ? ld4(grad.coef3 + K + kc) : f4(0.f);
-      rg[1] = affine ? ld4(grad.coef3 + 2 * K + kc) : f4(0.f);
-      rg[2] = affine ? ld4(grad.coef3 + 4 * K + kc) : f4(0.f);
-      rg[3] = affine ? ld4(grad.coef3 + 5 * K + kc) : f4(0.f);
-    } else {
-      rsc = src.coef ? ld4(src.coef + kc) : f4(1.f);
-      rsh = src.coef ? ld4(src.coef + K + kc) : f4(0.f);
-    }
+    kcur = kc;
 #pragma unroll
-    for (int i = 0; i < NT / 2; ++i) {
+    for (int i = 0; i < RW; ++i) {
       const int nr = r0 + 32 * i;
-      const bool in = kin && n0 + nr < N;
+      const bool in = kin && nr < NT * 16 && n0 + nr < N;
       rw[i] = ld4(W + (size_t)(in ? n0 + nr : 0) * d.ldw + kc);
       vin |= in ? (256u << i) : 0u;
     }
@@ -312,6 +304,18 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
   while (tile < ntiles) {
     // registers -> LDS (the input chunk normalised and clamped on the way), then request the next chunk so that its
     // memory round trip runs under this chunk's matrix products
+    float4 rsc, rsh, rg[GRAD ? 4 : 1];
+    if (GRAD) {   // dy = s*((dz - k1_hi) - k1_lo) + a2*((y - mean_hi) - mean_lo)
+      rsc = affine ? ld4(grad.coef3 + kcur) : f4(1.f);
+      rsh = affine ? ld4(grad.coef3 + 3 * K + kcur) : f4(0.f);
+      rg[0] = affine ? ld4(grad.coef3 + K + kcur) : f4(0.f);
+      rg[1] = affine ? ld4(grad.coef3 + 2 * K + kcur) : f4(0.f);
+      rg[2] = affine ? ld4(grad.coef3 + 4 * K + kcur) : f4(0.f);
+      rg[3] = affine ? ld4(grad.coef3 + 5 * K + kcur) : f4(0.f);
+    } else {
+      rsc = src.coef ? ld4(src.coef + kcur) : f4(1.f);
+      rsh = src.coef ? ld4(src.coef + K + kcur) : f4(0.f);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float4 v;
@@ -320,7 +324,8 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
       st4(As + (r0 + 32 * i) * PWG_PITCH + 4 * kq, ((vin >> i) & 1u) ? v : f4(0.f));
     }
 #pragma unroll
-    for (int i = 0; i < NT / 2; ++i) st4(Ws + (r0 + 32 * i) * PWG_PITCH + 4 * kq, ((vin >> (8 + i)) & 1u) ? rw[i] : f4(0.f));
+    for (int i = 0; i < RW; ++i)
+      if (NT % 2 == 0 || r0 + 32 * i < NT * 16) st4(Ws + (r0 + 32 * i) * PWG_PITCH + 4 * kq, ((vin >> (8 + i)) & 1u) ? rw[i] : f4(0.f));
     __syncthreads();
     long ntile = tile;
     int nch = ch + 1;
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
             st4(out + (size_t)pix * N + n, o);
             s1[m] = s1[m] + o;
             s2[m] = fma4(o, xh, s2[m]);
+            asm volatile("" ::: "memory");   // one channel tile's six operand vectors at a time, not all NT tiles' at once
           } else {
             st4(out + (size_t)pix * N + n, o);
             s1[m] = s1[m] + o;
@@ -402,6 +408,28 @@ __global__ __launch_bounds__(256) void ofa_pw_kernel(LazySrc src, LazyGrad grad,
       slab[(size_t)blockIdx.y * 2 * N + (size_t)j * N + n0 + c] = s;
     }
   }
+}
+
+// Channel tiles (of 16) per workgroup for N output channels: the instantiated count (1, 2, 4, 6, 8) that pads N the
+// least, among those that split N into at most one column group more than 128-channel groups would (every column group
+// stages the input tile again); ties go to the larger count.  Padding is matrix-core work: 96 channels as one group of
+// 128 spends a third of the MFMAs on zeros, 16 channels as a group of 64 three quarters.  Small problems (under two
+// workgroups per CU with 128-channel groups) take at most 64 channels per workgroup.
+inline int pw_channel_tiles(int N, long ntiles) {
+  static const int cand[5] = {1, 2, 4, 6, 8};
+  const int max_groups = noise_cdiv(N, 128) + 1;
+  const bool small = ntiles * noise_cdiv(N, 128) < 512;
+  int best = 8, best_pad = 1 << 30;
+  for (int c = 0; c < 5; ++c) {
+    const int nt = cand[c], groups = noise_cdiv(N, nt * 16), padded = groups * nt * 16;
+    if (small && nt > 4) continue;
+    if (groups > max_groups && !(small && nt == 4)) continue;
+    if (padded <= best_pad) {
+      best_pad = padded;
+      best = nt;
+    }
+  }
+  return best;
 }
 
 // ---- block output: BatchNorm (+ReLU6) of a raw tensor, plus the residual input, plus the cropped skip -------------------
@@ -585,17 +613,19 @@ NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src
   const LazySrc src{src_y, src_coef, src_relu6};
   const PwGDims d{npix, K, N, ldw};
   const long ntiles = (npix + 63) / 64;
-  // 128 output channels per workgroup when that still gives the GPU two workgroups per CU, 64 otherwise
-  const bool wide = N > 64 && ntiles * noise_cdiv(N, 128) >= 512;
-  const int gx = noise_cdiv(N, wide ? 128 : 64);
+  const int nt = pw_channel_tiles(N, ntiles);
+  const int gx = noise_cdiv(N, nt * 16);
   int gy = pixel_rows(ntiles, 1);
   const int want = noise_cdiv(2048, gx);   // few enough pixel rows that gx x rows stays near two rounds of the GPU
   if (gy > want) gy = want;
   const LazyGrad none{nullptr, nullptr, nullptr};
-  if (wide)
-    hipLaunchKernelGGL((ofa_pw_kernel<8, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d, src);
-  else
-    hipLaunchKernelGGL((ofa_pw_kernel<4, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d, src);
+#define PW_CASE(T)                                                                                                      \
+  case T:                                                                                                               \
+    hipLaunchKernelGGL((ofa_pw_kernel<T, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d, \
+                       src);                                                                                            \
+    break;
+  switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(6) default: PW_CASE(8) }
+#undef PW_CASE
   *rows = gy;
   NOISE_CHECK_LAUNCH("noise_ofa_pw");
   return 0;
@@ -619,16 +649,19 @@ NOISE_EXPORT int noise_gen_pw_dgrad(const float* dz, const float* y_out, const f
   const LazyGrad grad{dz, y_out, coef3};
   const PwGDims d{npix, Cout, Cin, ldw};
   const long ntiles = (npix + 63) / 64;
-  const bool wide = Cin > 64 && ntiles * noise_cdiv(Cin, 128) >= 512;
-  const int gx = noise_cdiv(Cin, wide ? 128 : 64);
+  const int nt = pw_channel_tiles(Cin, ntiles);
+  const int gx = noise_cdiv(Cin, nt * 16);
   int gy = pixel_rows(ntiles, 1);
   const int want = noise_cdiv(2048, gx);
   if (gy > want) gy = want;
   float* st = epi_y ? slab : nullptr;
-  if (wide)
-    hipLaunchKernelGGL((ofa_pw_kernel<8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, st, d, epi);
-  else
-    hipLaunchKernelGGL((ofa_pw_kernel<4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, st, d, epi);
+#define PW_CASE(T)                                                                                                      \
+  case T:                                                                                                               \
+    hipLaunchKernelGGL((ofa_pw_kernel<T, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, st, d, \
+                       epi);                                                                                            \
+    break;
+  switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(6) default: PW_CASE(8) }
+#undef PW_CASE
   if (rows) *rows = gy;
   NOISE_CHECK_LAUNCH("noise_gen_pw_dgrad");
   return 0;

@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void tok_epilogue_kernel(const float* __restri
 // dropout: masked weights drop out of the numerator only, the kept ones are scaled by keep_scale = 1 / (1 - p).
 constexpr int ATT_KB = 128;
 
+// 16 consecutive keep bytes of a query's row (any alignment) as four words; only the first `count` are read from memory.
+// A thread walks its own row, so byte-sized loads would touch a different cache line in every lane for every key; the
+// 16-byte form takes a line in eight requests instead of 128.
+__device__ __forceinline__ void keep_bytes16(const unsigned char* p, int count, unsigned (&w)[4]) {
+  if (count >= 16) {
+    __builtin_memcpy(w, p, 16);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned v = 0;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        if (4 * e + bb < count) v |= (unsigned)p[4 * e + bb] << (8 * bb);
+      w[e] = v;
+    }
+  }
+}
+
 template <int DKP>
 __global__ __launch_bounds__(256) void tok_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, int ld,
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(256) void tok_attention_kernel(const float* __restr
   __shared__ float Ks[ATT_KB * DKP];
   __shared__ float Vs[ATT_KB * DKP];
   const int h = blockIdx.y, b = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   const size_t row0 = (size_t)b * n;
   float qr[DKP], acc[DKP];
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(256) void tok_attention_kernel(const float* __restr
   const unsigned char* kp = keep ? keep + (((size_t)b * H + h) * n + (live ? i : 0)) * n : nullptr;
   for (int j0 = 0; j0 < n; j0 += ATT_KB) {
     __syncthreads();
-    for (int e = threadIdx.x; e < ATT_KB * DKP; e += 256) {
+    for (int e = threadIdx.x; e < ATT_KB * DKP; e += blockDim.x) {
       const int j = e / DKP, d = e - j * DKP;
       const bool in = j0 + j < n && d < dk;
       Ks[e] = in ? k[(row0 + j0 + j) * ld + h * dk + d] : 0.f;
@@ -124,22 +142,31 @@ __global__ __launch_bounds__(256) void tok_attention_kernel(const float* __restr
     }
     __syncthreads();
     const int jn = n - j0 < ATT_KB ? n - j0 : ATT_KB;
-    for (int j = 0; j < jn; ++j) {
-      float s = 0.f;
+    for (int jb = 0; jb < jn; jb += 16) {
+      const int kn = jn - jb < 16 ? jn - jb : 16;
+      unsigned kw[4];
+      if (kp) keep_bytes16(kp + j0 + jb, kn, kw);
 #pragma unroll
-      for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
-      if (s > m) {
-        const float c = expf(m - s);   // 0 on the first key (m = -inf)
-        l *= c;
+      for (int jj = 0; jj < 16; ++jj) {
+        if (jj < kn) {   // the same for every lane
+          const int j = jb + jj;
+          float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < DKP; ++d) acc[d] *= c;
-        m = s;
+          for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
+          if (s > m) {
+            const float c = expf(m - s);   // 0 on the first key (m = -inf)
+            l *= c;
+#pragma unroll
+            for (int d = 0; d < DKP; ++d) acc[d] *= c;
+            m = s;
+          }
+          const float p = expf(s - m);
+          l += p;
+          const float pk = kp ? (((kw[jj >> 2] >> (8 * (jj & 3))) & 0xffu) ? p * keep_scale : 0.f) : p;
+#pragma unroll
+          for (int d = 0; d < DKP; ++d) acc[d] = fmaf(pk, Vs[j * DKP + d], acc[d]);
+        }
       }
-      const float p = expf(s - m);
-      l += p;
-      const float pk = kp ? (kp[j0 + j] ? p * keep_scale : 0.f) : p;
-#pragma unroll
-      for (int d = 0; d < DKP; ++d) acc[d] = fmaf(pk, Vs[j * DKP + d], acc[d]);
     }
   }
   if (live) {
@@ -202,11 +229,13 @@ NOISE_EXPORT int noise_tok_attention(const float* q, const float* k, const float
   NOISE_REQUIRE(B > 0 && n > 0 && H > 0 && dk > 0 && dk <= 64, "noise_tok_attention: head size must be in 1..64 (got %d)", dk);
   NOISE_REQUIRE(B <= 65535 && H <= 65535, "noise_tok_attention: more than 65535 clips or heads in one call");
   NOISE_REQUIRE(ld >= H * dk && ldo >= H * dk && temperature > 0.f, "noise_tok_attention: bad strides or temperature");
-  const dim3 grid(noise_cdiv(n, 256), H, B);
+  // short clips: workgroups of 64 or 128 queries, so that few lanes are left without a query
+  const int nt = n <= 64 ? 64 : (n <= 128 ? 128 : 256);
+  const dim3 grid(noise_cdiv(n, nt), H, B);
   hipStream_t st = (hipStream_t)stream;
   const float it = 1.f / temperature;
 #define ATT_CASE(P)                                                                                                     \
-  hipLaunchKernelGGL(tok_attention_kernel<P>, grid, dim3(256), 0, st, q, k, v, ld, keep, keep_scale, out, ldo, n, H, dk, it)
+  hipLaunchKernelGGL(tok_attention_kernel<P>, grid, dim3(nt), 0, st, q, k, v, ld, keep, keep_scale, out, ldo, n, H, dk, it)
   if (dk <= 8) ATT_CASE(8);
   else if (dk <= 16) ATT_CASE(16);
   else if (dk <= 24) ATT_CASE(24);

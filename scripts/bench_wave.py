@@ -79,6 +79,10 @@ if L == 8000:
           f" peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     for name, (t, nb, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         print(f"   {name:26s} {t:8.3f} ms  {n:4d} calls  {nb / 1e6:9.1f} MB  {nb / 1e6 / max(t, 1e-9):8.1f} GB/s")
+    if os.environ.get("NOISE_WAVE_CALLS"):   # every launch of the step, in order
+        for i, (name, nbytes, a, b) in enumerate(prof):
+            t = a.elapsed_time(b)
+            print(f"   #{i:3d} {name:26s} {t:7.3f} ms {nbytes / 1e6:9.1f} MB {nbytes / 1e6 / max(t, 1e-9):8.1f} GB/s")
     print(json.dumps({"wave_unet_train_step": {"segments": B, "samples": L, "ms": round(ms, 3),
                                                "audio_s_per_s": round(B * L / 16000 / ms * 1e3, 1)}}))
 

@@ -34,7 +34,14 @@ def lazy_grad(g, npix, C, affine):
 
 @pytest.mark.parametrize("npix,Cout,Cin,affine,relu6", [(1000, 576, 96, True, True), (777, 16, 32, False, False),
                                                         (4100, 128, 576, True, True), (333, 20, 12, True, False),
-                                                        (64, 384, 128, False, True)])
+                                                        (64, 384, 128, False, True),
+                                                        # every blocking of the weight-gradient kernel (which operand the
+                                                        # waves split, 1..16 channel tiles of the other) and of the 1x1 kernel
+                                                        (1500, 16, 144, True, True), (1500, 144, 16, True, False),
+                                                        (2000, 96, 576, True, True), (900, 128, 768, False, True),
+                                                        (900, 768, 128, True, True), (3000, 24, 24, True, True),
+                                                        (700, 4, 8, True, True), (2100, 36, 20, False, False),
+                                                        (5000, 64, 384, True, True), (31, 192, 32, True, True)])
 def test_pw_dgrad_and_wgrad(npix, Cout, Cin, affine, relu6):
     from noise_amd import generic_train as gt
     g = torch.Generator().manual_seed(npix)
