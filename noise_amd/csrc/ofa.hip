@@ -250,16 +250,24 @@ constexpr int PWG_KC = 32, PWG_PITCH = 36;
 // activation, which makes the same product the input gradient of a 1x1 layer (W = the layer's weight transposed).
 // slab == nullptr skips the statistics.
 template <int NT, bool GRAD>
-__global__ __launch_bounds__(256, (GRAD && NT == 8) ? 2 : (NT <= 4 && !GRAD ? 4 : 3)) void ofa_pw_kernel(LazySrc src, LazyGrad grad, const float* __restrict__ W,
+__global__ __launch_bounds__(256, (GRAD && NT >= 6) ? 2 : (NT <= 4 && !GRAD ? 4 : 3)) void ofa_pw_kernel(LazySrc src, LazyGrad grad, const float* __restrict__ W,
                                                      float* __restrict__ out, float* __restrict__ slab, PwGDims d,
                                                      LazySrc epi) {
   __shared__ float As[64 * PWG_PITCH];
   __shared__ float Ws[NT * 16 * PWG_PITCH];
   __shared__ float red[4 * 2 * NT * 16];
+  __shared__ float ecf[GRAD ? 5 * NT * 16 : 4];   // backward epilogue: scale, shift, mean, invstd, mean_lo of this workgroup's channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, q = lane >> 4;
   const int K = d.K, N = d.N;
   const int n0 = blockIdx.x * NT * 16;
+  const bool has_epi = GRAD && epi.y != nullptr;
+  if (has_epi) {   // visible after the first barrier of the tile loop; a workgroup without tiles never reads it
+    for (int i = tid; i < 5 * NT * 16; i += 256) {
+      const int r = i / (NT * 16), c = i - r * (NT * 16);
+      ecf[i] = n0 + c < N ? epi.coef[r * N + n0 + c] : 0.f;
+    }
+  }
   const float alo = src.relu6 ? 0.f : -INFINITY, ahi = src.relu6 ? 6.f : INFINITY;
   float4 s1[NT], s2[NT];
 #pragma unroll
@@ -338,6 +346,15 @@ __global__ __launch_bounds__(256, (GRAD && NT == 8) ? 2 : (NT <= 4 && !GRAD ? 4 
 #pragma unroll
       for (int m = 0; m < NT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    float4 yr[GRAD ? NT : 1];
+    if (has_epi && ch == nchunk - 1) {   // the epilogue's raw tile arrives while the last chunk is multiplied
+      const long pix = tile * 64 + 16 * wave + p;
+#pragma unroll
+      for (int m = 0; m < (GRAD ? NT : 0); ++m) {
+        const int n = n0 + 16 * m + 4 * q;
+        yr[m] = ld4(epi.y + (size_t)(pix < d.npix ? pix : 0) * N + (n < N ? n : 0));
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < PWG_KC / 4; ++ks) {
       const float bv = As[(16 * wave + p) * PWG_PITCH + 4 * ks + q];
@@ -353,22 +370,22 @@ __global__ __launch_bounds__(256, (GRAD && NT == 8) ? 2 : (NT <= 4 && !GRAD ? 4 
         const int n = n0 + 16 * m + 4 * q;
         float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         if (pix < d.npix && n < N) {
-          if (GRAD && epi.y != nullptr) {
+          if (has_epi) {
             // backward epilogue: `out` is the gradient of the activated output of the BatchNorm (+ReLU6) whose raw
             // input is epi.y; mask it and leave that BatchNorm's two backward sums (sum g, sum g * xhat) in the slab
-            const float4 yraw = ld4(epi.y + (size_t)pix * N + n);
+            const float4 yraw = yr[GRAD ? m : 0];
+            const float* ec = ecf + 16 * m + 4 * q;
             if (epi.relu6) {
-              const float4 v = fma4(yraw, ld4(epi.coef + n), ld4(epi.coef + N + n));
+              const float4 v = fma4(yraw, ld4(ec), ld4(ec + NT * 16));
               o.x = (v.x > 0.f && v.x < 6.f) ? o.x : 0.f;
               o.y = (v.y > 0.f && v.y < 6.f) ? o.y : 0.f;
               o.z = (v.z > 0.f && v.z < 6.f) ? o.z : 0.f;
               o.w = (v.w > 0.f && v.w < 6.f) ? o.w : 0.f;
             }
-            const float4 xh = sub4(sub4(yraw, ld4(epi.coef + 2 * N + n)), ld4(epi.coef + 4 * N + n)) * ld4(epi.coef + 3 * N + n);
+            const float4 xh = sub4(sub4(yraw, ld4(ec + 2 * NT * 16)), ld4(ec + 4 * NT * 16)) * ld4(ec + 3 * NT * 16);
             st4(out + (size_t)pix * N + n, o);
             s1[m] = s1[m] + o;
             s2[m] = fma4(o, xh, s2[m]);
-            asm volatile("" ::: "memory");   // one channel tile's six operand vectors at a time, not all NT tiles' at once
           } else {
             st4(out + (size_t)pix * N + n, o);
             s1[m] = s1[m] + o;
