@@ -355,12 +355,25 @@ __global__ __launch_bounds__(256, (GRAD && NT >= 6) ? 2 : (NT <= 4 && !GRAD ? 4 
         yr[m] = ld4(epi.y + (size_t)(pix < d.npix ? pix : 0) * N + (n < N ? n : 0));
       }
     }
+    {
+      // Which input channel a lane feeds to which of the chunk's eight matrix products is free as long as both operands
+      // agree: lane quarter q takes channels 8q .. 8q+7, one per product, so each operand row is two 16-byte LDS reads
+      // (rows 36 floats apart put the 16 lanes of a quarter on disjoint banks) instead of eight 4-byte ones.
+      const float* ar = As + (16 * wave + p) * PWG_PITCH + 8 * q;
+      const float4 b0 = ld4(ar), b1 = ld4(ar + 4);
 #pragma unroll
-    for (int ks = 0; ks < PWG_KC / 4; ++ks) {
-      const float bv = As[(16 * wave + p) * PWG_PITCH + 4 * ks + q];
-#pragma unroll
-      for (int m = 0; m < NT; ++m)
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * m + p) * PWG_PITCH + 4 * ks + q], bv, acc[m], 0, 0, 0);
+      for (int m = 0; m < NT; ++m) {
+        const float* wr = Ws + (16 * m + p) * PWG_PITCH + 8 * q;
+        const float4 w0 = ld4(wr), w1 = ld4(wr + 4);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, b0.x, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, b0.y, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, b0.z, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, b0.w, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, b1.x, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, b1.y, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, b1.z, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, b1.w, acc[m], 0, 0, 0);
+      }
     }
     __syncthreads();
     if (ch == nchunk - 1) {
