@@ -198,6 +198,72 @@ __global__ __launch_bounds__(256) void ofa_dw1_kernel(LazySrc src, const float* 
   cv_stats(L, C, d.cl, s1, s2, slab);
 }
 
+// Stride 2, plain or transposed: a thread owns 4 channels of 2 consecutive output columns.  Plain: a filter row costs
+// K + 2 source loads for 2 K multiply-adds.  Transposed: output column 2x + par takes the taps kx = par + pad (mod 2)
+// from source columns x + (par + pad - kx) / 2, so the pair shares its (pad + 1) / 2 + pad / 2 + 1 source columns and
+// no tap is tested at run time.  Taps are summed in the order of ofa_dw_kernel (ky, then kx ascending), so the two
+// kernels agree bit for bit.
+template <int K, bool TR>
+__global__ __launch_bounds__(256) void ofa_dw2_kernel(LazySrc src, const float* __restrict__ wt, float* __restrict__ out,
+                                                      float* __restrict__ slab, DwDims d) {
+  const CvLane L = cv_lane(d.C, d.cl);
+  const Lazy4 a = lazy4_init(src, d.C, L.c);
+  constexpr int pad = K / 2;
+  constexpr int OMIN = -(pad / 2), NIN = TR ? (pad + 1) / 2 - OMIN + 1 : K + 2;
+  const int C = d.C;
+  const unsigned WP = (unsigned)(d.Wo + 1) >> 1, npair = (unsigned)d.B * d.Ho * WP;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  for (unsigned pr = blockIdx.y * L.PL + L.pl; pr < npair; pr += gridDim.y * L.PL) {
+    const unsigned t = pr / WP;
+    const int x = (int)(pr - t * WP), b = (int)(t / (unsigned)d.Ho), ho = (int)(t - (unsigned)b * d.Ho);
+    int ky_lo, ky_hi;
+    if (TR) {
+      ky_lo = max(0, ho + pad - 2 * (d.Hi - 1));
+      ky_lo += (ho + pad - ky_lo) & 1;
+      ky_hi = min(K - 1, ho + pad);
+    } else {
+      ky_lo = max(0, pad - 2 * ho);
+      ky_hi = min(K - 1, d.Hi - 1 + pad - 2 * ho);
+    }
+    float4 acc[2] = {f4(0.f), f4(0.f)};
+    for (int ky = ky_lo; ky <= ky_hi; ky += TR ? 2 : 1) {
+      const int iy = TR ? (ho + pad - ky) >> 1 : 2 * ho - pad + ky;
+      const float* rowp = a.y + ((size_t)b * d.Hi + iy) * d.Wi * C + L.c;
+      float4 in[NIN], w[K];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) w[kx] = ld4(wt + (size_t)(ky * K + kx) * C + L.c);
+#pragma unroll
+      for (int u = 0; u < NIN; ++u) {
+        const int ix = TR ? x + OMIN + u : 4 * x - pad + u;
+        const bool v = ix >= 0 && ix < d.Wi;
+        const float4 r = lazy4_act(a, ld4(rowp + (size_t)(v ? ix : 0) * C));
+        in[u] = make_float4(v ? r.x : 0.f, v ? r.y : 0.f, v ? r.z : 0.f, v ? r.w : 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          if (TR) {
+            if (((kx - j - pad) & 1) == 0) acc[j] = fma4(in[(j + pad - kx) / 2 - OMIN], w[kx], acc[j]);
+          } else {
+            acc[j] = fma4(in[2 * j + kx], w[kx], acc[j]);
+          }
+        }
+    }
+    if (L.ok) {
+      float* o = out + (((size_t)b * d.Ho + ho) * d.Wo + 2 * x) * C + L.c;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (2 * x + j < d.Wo) {
+          st4(o + (size_t)j * C, acc[j]);
+          s1 = s1 + acc[j];
+          s2 = fma4(acc[j], acc[j], s2);
+        }
+    }
+  }
+  cv_stats(L, C, d.cl, s1, s2, slab);
+}
+
 // ---- the active depthwise filter (layers.py:162-196), written tap-major: wt[tap][c] ---------------------------------------
 // A block takes 64 channels: the filters sit in LDS, and each step (centre crop of the current filter, times the transform
 // matrix: y_j = sum_i x_i M[j][i]) runs with one thread per (channel, output tap).
@@ -624,6 +690,19 @@ NOISE_EXPORT int noise_ofa_dw(const float* src_y, const float* src_coef, int src
     else hipLaunchKernelGGL(ofa_dw1_kernel<7>, g1, dim3(256), 0, st, src, wt, out, slab, d);
     NOISE_CHECK_LAUNCH("noise_ofa_dw");
     *rows = (int)g1.y;
+    return 0;
+  }
+  if (stride == 2 && k >= 3 && (long)B * Ho * ((Wo + 1) / 2) < (1L << 31)) {
+    const dim3 g2(grid.x, pixel_rows((long)B * Ho * ((Wo + 1) / 2), 256 / d.cl));
+#define DW2_CASE(KK)                                                                                                    \
+  if (transposed) hipLaunchKernelGGL((ofa_dw2_kernel<KK, true>), g2, dim3(256), 0, st, src, wt, out, slab, d);             \
+  else hipLaunchKernelGGL((ofa_dw2_kernel<KK, false>), g2, dim3(256), 0, st, src, wt, out, slab, d)
+    if (k == 3) { DW2_CASE(3); }
+    else if (k == 5) { DW2_CASE(5); }
+    else { DW2_CASE(7); }
+#undef DW2_CASE
+    NOISE_CHECK_LAUNCH("noise_ofa_dw");
+    *rows = (int)g2.y;
     return 0;
   }
   if (transposed)

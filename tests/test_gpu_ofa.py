@@ -88,7 +88,9 @@ def test_layers_against_torch():
         stats(out, N)
     # depthwise, every kernel size / stride / direction
     for C, k, s, tr, Hi, Wi in ((24, 7, 2, False, 19, 11), (24, 7, 2, True, 9, 6), (200, 5, 1, False, 7, 9), (200, 5, 1, True, 7, 9),
-                                (8, 3, 2, True, 13, 5), (1152, 3, 2, False, 6, 4), (40, 7, 1, True, 3, 3)):
+                                (8, 3, 2, True, 13, 5), (1152, 3, 2, False, 6, 4), (40, 7, 1, True, 3, 3),
+                                (16, 3, 2, False, 1, 37), (16, 3, 2, True, 1, 18), (96, 5, 2, False, 4, 10), (96, 5, 2, True, 4, 7),
+                                (36, 3, 2, False, 5, 1), (36, 3, 2, True, 2, 1), (576, 3, 2, True, 1, 63), (576, 3, 2, False, 1, 126)):
         B = 2
         a = torch.randn(B, Hi, Wi, C, device=dev, generator=g)
         coef = torch.cat([torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)])
