@@ -186,10 +186,31 @@ __global__ __launch_bounds__(256) void gen_colsum_kernel(const float* __restrict
   const long chunk = (M + gridDim.x - 1) / gridDim.x;
   const long m0 = (long)blockIdx.x * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
   if (N >= 64) {   // a thread owns columns tid, tid + 256, ...
-    for (int c = threadIdx.x; c < N; c += 256) {
+    // the 256 threads split into column lanes and row lanes (N = 128: two row lanes), eight loads in flight per thread;
+    // the row lanes' partials meet in LDS in a fixed order
+    const int CL = N >= 256 ? 256 : (N >= 128 ? 128 : 64), RL = 256 / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    for (int c0 = 0; c0 < N; c0 += CL) {
+      const int c = c0 + cl;
       float s = 0.f;
-      for (long m = m0; m < m1; ++m) s += x[(size_t)m * ld + c];
-      slab[(size_t)blockIdx.x * N + c] = s;
+      if (c < N) {
+        long m = m0 + rl;
+        float t[8];
+        for (; m + 7 * RL < m1; m += 8 * RL) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = x[(size_t)(m + u * RL) * ld + c];
+          s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        for (; m < m1; m += RL) s += x[(size_t)m * ld + c];
+      }
+      __syncthreads();
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (rl == 0 && c < N) {
+        float sum = red[cl];
+        for (int r = 1; r < RL; ++r) sum += red[r * CL + cl];
+        slab[(size_t)blockIdx.x * N + c] = sum;
+      }
     }
   } else {         // narrow matrices: the threads split the rows, then fold in a fixed order
     for (int c = 0; c < N; ++c) {
