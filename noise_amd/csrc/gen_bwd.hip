@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict
 // ds_ij = p_ij (dp_ij - D_i), dp_ij = keep_ij * keep_scale * (dO_i . v_j).  The three statistics are kept for pass KV (a
 // thread owns a key): dv_j = sum_i p_ij keep_ij keep_scale dO_i, dk_j = sum_i ds_ij q_i / T.  No atomics.
 constexpr int ATB_KB = 128;
+constexpr float LOG2E = 1.44269504088896341f;
 
 // 16 consecutive keep bytes of a query's row (any alignment) as four words; only the first `count` are read from memory
 // (byte-sized loads along a thread's own row touch a different cache line in every lane for every key).
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __rest
 #pragma unroll
   for (int d = 0; d < DKP; ++d) {
     const bool in = live && d < dk;
-    qr[d] = in ? q[(row0 + ic) * ld + h * dk + d] * inv_temp : 0.f;
+    qr[d] = in ? q[(row0 + ic) * ld + h * dk + d] * (inv_temp * LOG2E) : 0.f;   // scores in units of log2: exp is v_exp_f32
     gr[d] = in ? go[(row0 + ic) * ldo + h * dk + d] : 0.f;
     Di = fmaf(gr[d], in ? o[(row0 + ic) * ldo + h * dk + d] : 0.f, Di);
     acc[d] = 0.f;
@@ -393,10 +394,10 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __rest
 #pragma unroll
           for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
           if (s > m) {
-            l *= expf(m - s);
+            l *= __builtin_amdgcn_exp2f(m - s);
             m = s;
           }
-          l += expf(s - m);
+          l += __builtin_amdgcn_exp2f(s - m);
         }
       } else {
         for (int jb = 0; jb < jn; jb += 16) {
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_q_kernel(const float* __rest
               float s = 0.f;
 #pragma unroll
               for (int d = 0; d < DKP; ++d) s = fmaf(qr[d], Ks[j * DKP + d], s);
-              const float pj = expf(s - m) * rl;
+              const float pj = __builtin_amdgcn_exp2f(s - m) * rl;
               float dp = 0.f;
 #pragma unroll
               for (int d = 0; d < DKP; ++d) dp = fmaf(gr[d], Vs[j * DKP + d], dp);
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kv_kernel(const float* __res
             s = fmaf(Qs[i * DKP + d], kr[d], s);
             dp = fmaf(Gs[i * DKP + d], vr[d], dp);
           }
-          const float pj = expf(s - St[3 * i]) * St[3 * i + 1];
+          const float pj = __builtin_amdgcn_exp2f(s * LOG2E - St[3 * i]) * St[3 * i + 1];   // the stored maximum is in units of log2
           float pm = pj;
           if (kp) {
             const bool kept = kb[ii] != 0;

@@ -177,6 +177,145 @@ __global__ __launch_bounds__(256) void tok_attention_kernel(const float* __restr
   }
 }
 
+// The same attention on the matrix cores (head size up to 32): fp32 v_mfma_f32_16x16x4_f32 tiles with the online softmax,
+// so the n x n scores are neither stored nor recomputed.  A workgroup of eight waves owns 256 queries of one (clip, head),
+// a wave two tiles of 16; the keys and values pass through LDS 64 at a time.  Per 16 keys and query tile:
+//     S^T tile [key][query] = K Q^T         (DK4 products; a lane ends up with 4 consecutive keys of one query)
+//     running max / rescale / p = exp(s-m)  (the maximum over a query's 16 keys: in-lane, then two shuffles; the scores
+//                                            carry a factor log2(e) from the query operand, so exp is one v_exp_f32:
+//                                            with the library expf the kernel spent more time there than in the products)
+//     O^T [d][query] += V^T P^T             (4 products per 16 output columns; k-step s takes key 4q + s, the lane's own
+//                                            register s, so P feeds the next product without moving)
+// The keep mask of a lane's 4 keys is one 4-byte load.  Row pitches (DKP + 4 and 16 DT + 4 floats) put the 64 lanes of
+// every operand read on 64 different banks.
+constexpr int ATM_KB = 64, ATM_QT = 2;
+
+// maximum over the lanes p, p + 16, p + 32, p + 48 (a query's four key groups): the two row-swap instructions of gfx950
+// instead of two round trips through the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32 and a wait)
+__device__ __forceinline__ float max_over_quarters(float v) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(v);
+  u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int DK4, int DT>
+__global__ __launch_bounds__(512) void tok_attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, int ld,
+                                                                 const unsigned char* __restrict__ keep, float keep_scale,
+                                                                 float* __restrict__ out, int ldo, int n, int H, int dk,
+                                                                 float inv_temp) {
+  constexpr int DKP = 4 * DK4, KP = DKP + 4, VP = 16 * DT + 4;
+  __shared__ float ks[ATM_KB * KP];
+  __shared__ float vs[ATM_KB * VP];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, qd = lane >> 4;
+  const size_t row0 = (size_t)b * n;
+  int qi[ATM_QT];
+  float qreg[ATM_QT][DK4];
+  f32x4 acc[ATM_QT][DT];
+  float m[ATM_QT], l[ATM_QT];
+  const unsigned char* kp[ATM_QT];
+#pragma unroll
+  for (int t = 0; t < ATM_QT; ++t) {
+    qi[t] = blockIdx.x * (16 * ATM_QT * 8) + (wave * ATM_QT + t) * 16 + p;
+    const int qc = qi[t] < n ? qi[t] : n - 1;
+    const float* qrow = q + (row0 + qc) * ld + h * dk;
+#pragma unroll
+    for (int kk = 0; kk < DK4; ++kk) qreg[t][kk] = (4 * kk + qd < dk) ? qrow[4 * kk + qd] * (inv_temp * 1.44269504088896341f) : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+    kp[t] = keep ? keep + (((size_t)b * H + h) * n + qc) * n : nullptr;
+  }
+  for (int j0 = 0; j0 < n; j0 += ATM_KB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < ATM_KB * DKP; e += 512) {
+      const int j = e / DKP, d = e - j * DKP;
+      const bool in = j0 + j < n && d < dk;
+      const size_t at = (row0 + (j0 + j < n ? j0 + j : n - 1)) * ld + h * dk + (d < dk ? d : 0);
+      const float kv = k[at], vv = v[at];
+      ks[j * KP + d] = in ? kv : 0.f;
+      if (d < 16 * DT) vs[j * VP + d] = in ? vv : 0.f;
+    }
+    if (DKP < 16 * DT) {   // value columns the key loop above does not reach
+      for (int e = threadIdx.x; e < ATM_KB * (16 * DT - DKP); e += 512) {
+        const int j = e / (16 * DT - DKP), d = DKP + e - j * (16 * DT - DKP);
+        vs[j * VP + d] = 0.f;
+      }
+    }
+    __syncthreads();
+    const int nkt = (min(n - j0, ATM_KB) + 15) >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key0 = 16 * kt;
+      float ka[DK4];
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk) ka[kk] = ks[(key0 + p) * KP + 4 * kk + qd];
+      float va[4][DT];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) va[s2][dt] = vs[(key0 + 4 * qd + s2) * VP + 16 * dt + p];
+      const int kleft = n - (j0 + key0 + 4 * qd);   // keys of this lane that exist (may be <= 0 or >= 4)
+#pragma unroll
+      for (int t = 0; t < ATM_QT; ++t) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK4; ++kk) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kk], qreg[t][kk], st, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r >= kleft) st[r] = -INFINITY;
+        const float bm = max_over_quarters(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+        const float mn = fmaxf(m[t], bm);        // finite: every tile visited holds at least one existing key
+        const float sc = __builtin_amdgcn_exp2f(m[t] - mn);
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(st[r] - mn);
+        l[t] = l[t] * sc + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+        if (kp[t]) {
+          unsigned kw = 0;
+          const unsigned char* kb = kp[t] + j0 + key0 + 4 * qd;
+          if (kleft >= 4) __builtin_memcpy(&kw, kb, 4);
+          else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+              if (r < kleft) kw |= (unsigned)kb[r] << (8 * r);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pr[r] = ((kw >> (8 * r)) & 0xffu) ? pr[r] * keep_scale : 0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][dt][r] *= sc;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[s2][dt], pr[s2], acc[t][dt], 0, 0, 0);
+        }
+        m[t] = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < ATM_QT; ++t) {
+    float lt = l[t];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    if (qi[t] < n) {
+      const float inv = 1.f / lt;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * dt + 4 * qd + r;
+          if (c < dk) out[(row0 + qi[t]) * ldo + h * dk + c] = acc[t][dt][r] * inv;
+        }
+    }
+  }
+}
+
 // ---- voice-activity logit of a clip from its first token (models.py:601): one wave per clip --------------------------------
 __global__ __launch_bounds__(64) void tok_vad_kernel(const float* __restrict__ x, int ld, long tokens_per_clip,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
@@ -236,6 +375,21 @@ NOISE_EXPORT int noise_tok_attention(const float* q, const float* k, const float
   const float it = 1.f / temperature;
 #define ATT_CASE(P)                                                                                                     \
   hipLaunchKernelGGL(tok_attention_kernel<P>, grid, dim3(nt), 0, st, q, k, v, ld, keep, keep_scale, out, ldo, n, H, dk, it)
+  // heads of at most 32 run on the matrix cores (NOISE_TOK_ATT_VALU, diagnostic: the thread-per-query kernel)
+  static const bool valu_only = getenv("NOISE_TOK_ATT_VALU") != nullptr;
+  if (dk <= 32 && !valu_only) {
+    const dim3 gm(noise_cdiv(n, 16 * ATM_QT * 8), H, B);
+#define ATM_CASE(K4, T)                                                                                                 \
+  hipLaunchKernelGGL((tok_attention_mfma_kernel<K4, T>), gm, dim3(512), 0, st, q, k, v, ld, keep, keep_scale, out, ldo, n, \
+                     H, dk, it)
+    if (dk <= 8) ATM_CASE(2, 1);
+    else if (dk <= 16) ATM_CASE(4, 1);
+    else if (dk <= 24) ATM_CASE(6, 2);
+    else ATM_CASE(8, 2);
+#undef ATM_CASE
+    NOISE_CHECK_LAUNCH("noise_tok_attention");
+    return 0;
+  }
   if (dk <= 8) ATT_CASE(8);
   else if (dk <= 16) ATT_CASE(16);
   else if (dk <= 24) ATT_CASE(24);

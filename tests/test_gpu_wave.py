@@ -169,7 +169,8 @@ def P(t):
 
 
 @pytest.mark.parametrize("B,n,H,dk,p", [(2, 250, 6, 21, 0.0), (1, 700, 4, 8, 0.1), (3, 37, 3, 32, 0.25), (1, 129, 1, 1, 0.0),
-                                         (2, 300, 2, 40, 0.1)])
+                                         (2, 300, 2, 40, 0.1), (2, 251, 6, 21, 0.1), (1, 1031, 2, 10, 0.0), (1, 515, 2, 16, 0.2),
+                                         (2, 16, 2, 24, 0.0), (1, 65, 1, 5, 0.3), (1, 2500, 1, 21, 0.0)])
 def test_tok_attention(B, n, H, dk, p):
     g = torch.Generator().manual_seed(n)
     ld = 3 * H * dk + 5
