@@ -22,6 +22,10 @@ struct AttnDims {
   int heads, dk, hd;  // hd = heads*dk (<= 64)
 };
 
+// exp as one multiply and v_exp_f32 (the library expf is about twenty instructions; the softmax weights of every kernel
+// here, forward and backward, go through this one function, so they stay consistent with each other)
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 __device__ __forceinline__ float quad_sum(float v) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void attn_core_fwd_kernel(const float* __restr
       }
       if (act)
         for (int j = 0; j < cnt; ++j) {
-          const float e = expf(attn_dot(q, ks + j * dkp, dk4) - m);
+          const float e = exp_hw(attn_dot(q, ks + j * dkp, dk4) - m);
           l += e;
           if (keep_elem(keep, seed, p_drop, mrow + c0 + j)) attn_axpy(acc, e, vs + j * dkp, dk4);
         }
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* __restr
           const float sc = attn_dot(q, sa + j * dkp, dk4);
           float dp = attn_dot(go, sb + j * dkp, dk4);
           if (!keep_elem(keep, seed, p_drop, mrow + c0 + j)) dp = 0.f;
-          Di = fmaf(expf(sc - mi) * li, dp * inv_keep, Di);
+          Di = fmaf(exp_hw(sc - mi) * li, dp * inv_keep, Di);
         }
       }
     }
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* __restr
           const float sc = attn_dot(q, sa + j * dkp, dk4);
           float dp = attn_dot(go, sb + j * dkp, dk4);
           if (!keep_elem(keep, seed, p_drop, mrow + c0 + j)) dp = 0.f;
-          const float p = expf(sc - mi) * li;
+          const float p = exp_hw(sc - mi) * li;
           attn_axpy(dq, p * (dp * inv_keep - Di), sa + j * dkp, dk4);
         }
       }
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(const float* __restr
           const float sc = attn_dot(kr, sa + ii * dkp, dk4);
           const float dp = attn_dot(vr, sb + ii * dkp, dk4);
           const bool kp = keep_elem(keep, seed, p_drop, (((long)b * d.heads + h) * n + i) * n + j);
-          const float p = expf(sc - mm[i]) * ll[i];
+          const float p = exp_hw(sc - mm[i]) * ll[i];
           attn_axpy(dkk, p * ((kp ? dp * inv_keep : 0.f) - Dd[i]), sa + ii * dkp, dk4);
           attn_axpy(dvv, kp ? p * inv_keep : 0.f, sb + ii * dkp, dk4);
         }
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(AW) void attn_core_fwd_wave_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < AW; ++j) {
     if (j < n) {
-      const float e = expf(s[j] - m);
+      const float e = exp_hw(s[j] - m);
       l += e;
       if (keep_at<DROP>(keep, seed, p_drop, mrow + j)) axpy_row<DK4>(e, vs + j * DKP, acc);
     }
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
       const float sj = dot_row<DK4>(q, ks + j * DKP);
       const bool kp = keep_at<DROP>(keep, seed, p_drop, mrow + j);
       const float dp = kp ? dot_row<DK4>(dout, vs + j * DKP) : 0.f;
-      pr[j] = expf(sj - mi) * li;
+      pr[j] = exp_hw(sj - mi) * li;
       Di = fmaf(pr[j], dp * inv_keep, Di);
       kept |= kp ? (1ull << j) : 0ull;
       if (act) M[i * mp + j] = kp ? pr[j] * inv_keep : 0.f;
@@ -786,10 +790,10 @@ __global__ __launch_bounds__(1024) void attn_core_fwd_mfma_kernel(const float* _
       bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
       bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
       const float mn = fmaxf(m, bm);          // finite: every block holds at least one real key
-      const float sc = expf(m - mn);
+      const float sc = exp_hw(m - mn);
       float pr[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pr[r] = expf(st[r] - mn);
+      for (int r = 0; r < 4; ++r) pr[r] = exp_hw(st[r] - mn);
       l = l * sc + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] *= sc;
