@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict
 }
 
 // ---- attention backward (models.py:26-36): two passes, both recompute the scores ----------------------------------------------
-// Pass Q (a thread owns a query): softmax statistics (max, sum) and D_i = dO_i . O_i, then dq_i = sum_j ds_ij k_j / T with
+// Pass Q (a thread owns a query): softmax statistics (max of the scores in units of log2, sum) and D_i = dO_i . O_i, then dq_i = sum_j ds_ij k_j / T with
 // ds_ij = p_ij (dp_ij - D_i), dp_ij = keep_ij * keep_scale * (dO_i . v_j).  The three statistics are kept for pass KV (a
 // thread owns a key): dv_j = sum_i p_ij keep_ij keep_scale dO_i, dk_j = sum_i ds_ij q_i / T.  No atomics.
 constexpr int ATB_KB = 128;
