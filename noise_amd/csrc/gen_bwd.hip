@@ -621,11 +621,33 @@ NOISE_EXPORT int noise_gen_slab_reduce(const float* slab, int rows, long cols, f
 }
 
 // rows of the partial slab noise_gen_pw_wgrad writes for npix pixels (each Cout*Cin floats)
+// resident workgroups per CU of the instance a plan selects (cached)
+static int wgrad_per_cu(const WgradPlan& pl) {
+  static int cache[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  const int ci = pl.ct == 1 ? 0 : (pl.ct == 2 ? 1 : (pl.ct == 4 ? 2 : (pl.ct == 8 ? 3 : 4)));
+  int& v = cache[pl.swap ? 1 : 0][ci];
+  if (v == 0) {
+    int n = 0;
+    hipError_t e = hipErrorUnknown;
+#define WG_OCC(T)                                                                                                       \
+  case T:                                                                                                               \
+    e = pl.swap ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gen_pw_wgrad_kernel<T, true>, 256, 0)               \
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gen_pw_wgrad_kernel<T, false>, 256, 0);             \
+    break;
+    switch (pl.ct) { WG_OCC(1) WG_OCC(2) WG_OCC(4) WG_OCC(8) default: WG_OCC(16) }
+#undef WG_OCC
+    v = (e == hipSuccess && n >= 1) ? n : 3;
+  }
+  return v;
+}
+
 NOISE_EXPORT int noise_gen_pw_wgrad_rows(long npix, int Cout, int Cin) {
   const WgradPlan pl = wgrad_plan(Cout, Cin);
   const long ntiles = (npix + pl.pt - 1) / pl.pt;
-  // three workgroups per CU over the whole grid: more rows only lengthen the fold
-  long rows = noise_cdiv(768, (long)pl.nx * pl.ny);
+  // one round of resident workgroups over the whole grid: more rows only lengthen the fold, and a partly filled second
+  // round would cost a full one (every workgroup carries the same share of the tiles)
+  const long blocks = (long)pl.nx * pl.ny, round = (long)noise_num_cus() * wgrad_per_cu(pl);
+  long rows = round / blocks;
   const long cap = (64L << 20) / ((long)Cout * Cin * 4);   // at most 64 MiB of partials
   if (rows > cap) rows = cap;
   if (rows > ntiles) rows = ntiles;

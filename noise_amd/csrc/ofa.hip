@@ -528,6 +528,20 @@ inline int pw_channel_tiles(int N, long ntiles) {
   return best;
 }
 
+// Pixel rows of a gx x gy grid cut down to whole rounds of the GPU: workgroups walk their tiles with a fixed stride, so
+// all of them carry the same work and a last, partly filled round costs a full one (1024 workgroups over 768 resident
+// slots take two rounds at two thirds of the machine).  per_cu caches the kernel's resident workgroups per CU.
+template <typename KernelT>
+inline int whole_round_rows(KernelT kernel, int& per_cu, int gx, int gy) {
+  if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1))
+    per_cu = -1;
+  if (per_cu < 1) return gy;
+  const long round = (long)noise_num_cus() * per_cu, total = (long)gx * gy;
+  if (total <= round) return gy;
+  const long rows = total / round * round / gx;
+  return rows < 1 ? 1 : (int)rows;
+}
+
 // ---- block output: BatchNorm (+ReLU6) of a raw tensor, plus the residual input, plus the cropped skip -------------------
 // out[b][h][w][c] = act(scale*y[b][h+oy][w+ox][c] + shift) + res[b][h][w][c] + skip[b][h+sy][w+sx][c]
 // (layers.py:457-458 residual, :662 skip cropped from the end, :666 output crop).
@@ -729,10 +743,13 @@ NOISE_EXPORT int noise_ofa_pw(const float* src_y, const float* src_coef, int src
   if (gy > want) gy = want;
   const LazyGrad none{nullptr, nullptr, nullptr};
 #define PW_CASE(T)                                                                                                      \
-  case T:                                                                                                               \
+  case T: {                                                                                                             \
+    static int per_cu = 0;                                                                                              \
+    gy = whole_round_rows(ofa_pw_kernel<T, false>, per_cu, gx, gy);                                                     \
     hipLaunchKernelGGL((ofa_pw_kernel<T, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, none, W, out, slab, d, \
                        src);                                                                                            \
-    break;
+    break;                                                                                                              \
+  }
   switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(6) default: PW_CASE(8) }
 #undef PW_CASE
   *rows = gy;
@@ -765,10 +782,13 @@ NOISE_EXPORT int noise_gen_pw_dgrad(const float* dz, const float* y_out, const f
   if (gy > want) gy = want;
   float* st = epi_y ? slab : nullptr;
 #define PW_CASE(T)                                                                                                      \
-  case T:                                                                                                               \
+  case T: {                                                                                                             \
+    static int per_cu = 0;                                                                                              \
+    gy = whole_round_rows(ofa_pw_kernel<T, true>, per_cu, gx, gy);                                                      \
     hipLaunchKernelGGL((ofa_pw_kernel<T, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, none, grad, Wt, g_in, st, d, \
                        epi);                                                                                            \
-    break;
+    break;                                                                                                              \
+  }
   switch (nt) { PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(6) default: PW_CASE(8) }
 #undef PW_CASE
   if (rows) *rows = gy;
