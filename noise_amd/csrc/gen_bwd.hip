@@ -521,6 +521,346 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kv_kernel(const float* __res
   }
 }
 
+// ---- the same backward on the matrix cores (head size up to 32) -----------------------------------------------------------------
+// Both passes keep the score tiles in registers in the layout the fp32 MFMA leaves them in, which is the operand layout of
+// the next product (see tok_attention_mfma_kernel in wave.hip):
+//   pass Q  (a wave owns query tiles, keys stream through LDS): S^T = K Q^T and dP^T = V dO^T give a lane 4 keys of one
+//           query; ds = p (dp - D) feeds dQ^T += K^T dS^T with k = the lane's own keys.  A first sweep over the keys finds
+//           the softmax statistics (kept for pass KV with D_i = dO_i . O_i).
+//   pass KV (a wave owns key tiles, queries stream through LDS): S = Q K^T and dP = dO V^T give a lane 4 queries of one
+//           key; dV^T += dO^T P and dK^T += Q^T dS with k = the lane's own queries.
+// Scores carry log2(e), so exp is one v_exp_f32.  Rows of 36 floats put the 64 lanes of every operand read on 64 banks.
+constexpr int ABM_P = 36, ABM_BLK = 64, ABM_T = 2;
+
+__device__ __forceinline__ float max_over_quarters(float v) {   // over lanes p, p + 16, p + 32, p + 48
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(v);
+  u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_over_quarters(float v) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(v);
+  u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// rows j0 .. j0 + ABM_BLK - 1 of one head (dk columns from col0) on their way into a [ABM_BLK][ABM_P] tile, in two steps
+// so that a block's memory round trip runs under the previous block's products: abm_fetch requests them into registers
+// (columns dk .. CW - 1 and rows past n: zero), abm_put writes the registers to LDS (times scale).
+template <int CW>
+struct AbmRegs {
+  float v[ABM_BLK * CW / 512];
+};
+template <int CW>
+__device__ __forceinline__ void abm_fetch(AbmRegs<CW>& r, const float* __restrict__ src, size_t row0, int ld, int col0, int j0,
+                                          int n, int dk) {
+#pragma unroll
+  for (int i = 0; i < ABM_BLK * CW / 512; ++i) {
+    const int e = threadIdx.x + 512 * i, j = e / CW, d = e - j * CW;
+    const bool in = j0 + j < n && d < dk;
+    const float v = src[(row0 + (j0 + j < n ? j0 + j : n - 1)) * ld + col0 + (d < dk ? d : 0)];
+    r.v[i] = in ? v : 0.f;
+  }
+}
+template <int CW>
+__device__ __forceinline__ void abm_put(const AbmRegs<CW>& r, float* dst, float scale) {
+#pragma unroll
+  for (int i = 0; i < ABM_BLK * CW / 512; ++i) {
+    const int e = threadIdx.x + 512 * i, j = e / CW, d = e - j * CW;
+    dst[j * ABM_P + d] = r.v[i] * scale;
+  }
+}
+
+template <int DK4, int DT>
+__global__ __launch_bounds__(512) void gen_attn_bwd_q_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                  const float* __restrict__ v, int ld,
+                                                                  const unsigned char* __restrict__ keep, float keep_scale,
+                                                                  const float* __restrict__ o, const float* __restrict__ go,
+                                                                  int ldo, float* __restrict__ dq, float* __restrict__ stats,
+                                                                  int n, int H, int dk, float inv_temp) {
+  constexpr int CW = DK4 * 4 > 16 * DT ? DK4 * 4 : 16 * DT;
+  __shared__ float ks[ABM_BLK * ABM_P];
+  __shared__ float vs[ABM_BLK * ABM_P];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, qd = lane >> 4;
+  const size_t row0 = (size_t)b * n;
+  const float kscale = keep ? keep_scale : 1.f;   // without a mask nothing is rescaled
+  int qi[ABM_T];
+  float qreg[ABM_T][DK4], greg[ABM_T][DK4], m[ABM_T], l[ABM_T], Di[ABM_T];
+  const unsigned char* kp[ABM_T];
+#pragma unroll
+  for (int t = 0; t < ABM_T; ++t) {
+    qi[t] = blockIdx.x * (16 * ABM_T * 8) + (wave * ABM_T + t) * 16 + p;
+    const int qc = qi[t] < n ? qi[t] : n - 1;
+    const float* qrow = q + (row0 + qc) * ld + h * dk;
+    const float* grow = go + (row0 + qc) * ldo + h * dk;
+    const float* orow = o + (row0 + qc) * ldo + h * dk;
+    float dpart = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < DK4; ++kk) {
+      const int d = 4 * kk + qd;
+      const bool in = d < dk;
+      qreg[t][kk] = in ? qrow[d] * (inv_temp * LOG2E) : 0.f;
+      greg[t][kk] = in ? grow[d] : 0.f;
+      dpart = fmaf(greg[t][kk], in ? orow[d] : 0.f, dpart);
+    }
+    Di[t] = sum_over_quarters(dpart);
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+    kp[t] = keep ? keep + (((size_t)b * H + h) * n + qc) * n : nullptr;
+  }
+  AbmRegs<CW> rk, rv;
+  // ---- sweep 1: softmax statistics
+  abm_fetch<CW>(rk, k, row0, ld, h * dk, 0, n, dk);
+  for (int j0 = 0; j0 < n; j0 += ABM_BLK) {
+    __syncthreads();   // the previous block's products have read the tile
+    abm_put<CW>(rk, ks, 1.f);
+    __syncthreads();
+    if (j0 + ABM_BLK < n) abm_fetch<CW>(rk, k, row0, ld, h * dk, j0 + ABM_BLK, n, dk);
+    const int nkt = (min(n - j0, ABM_BLK) + 15) >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key0 = 16 * kt;
+      float ka[DK4];
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk) ka[kk] = ks[(key0 + p) * ABM_P + 4 * kk + qd];
+      const int kleft = n - (j0 + key0 + 4 * qd);
+#pragma unroll
+      for (int t = 0; t < ABM_T; ++t) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK4; ++kk) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kk], qreg[t][kk], st, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r >= kleft) st[r] = -INFINITY;
+        const float bm = max_over_quarters(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+        const float mn = fmaxf(m[t], bm);   // finite: the tile holds at least one existing key
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += __builtin_amdgcn_exp2f(st[r] - mn);
+        l[t] = l[t] * __builtin_amdgcn_exp2f(m[t] - mn) + sum;
+        m[t] = mn;
+      }
+    }
+  }
+  float rl[ABM_T];
+  f32x4 acc[ABM_T][DT];
+#pragma unroll
+  for (int t = 0; t < ABM_T; ++t) {
+    rl[t] = 1.f / sum_over_quarters(l[t]);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // ---- sweep 2: ds and dQ
+  abm_fetch<CW>(rk, k, row0, ld, h * dk, 0, n, dk);
+  abm_fetch<CW>(rv, v, row0, ld, h * dk, 0, n, dk);
+  for (int j0 = 0; j0 < n; j0 += ABM_BLK) {
+    __syncthreads();
+    abm_put<CW>(rk, ks, 1.f);
+    abm_put<CW>(rv, vs, 1.f);
+    __syncthreads();
+    if (j0 + ABM_BLK < n) {
+      abm_fetch<CW>(rk, k, row0, ld, h * dk, j0 + ABM_BLK, n, dk);
+      abm_fetch<CW>(rv, v, row0, ld, h * dk, j0 + ABM_BLK, n, dk);
+    }
+    const int nkt = (min(n - j0, ABM_BLK) + 15) >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key0 = 16 * kt;
+      float ka[DK4], va[DK4], kb[4][DT];
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk) {
+        ka[kk] = ks[(key0 + p) * ABM_P + 4 * kk + qd];
+        va[kk] = vs[(key0 + p) * ABM_P + 4 * kk + qd];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) kb[s2][dt] = ks[(key0 + 4 * qd + s2) * ABM_P + 16 * dt + p];
+      const int kleft = n - (j0 + key0 + 4 * qd);
+#pragma unroll
+      for (int t = 0; t < ABM_T; ++t) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK4; ++kk) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kk], qreg[t][kk], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[kk], greg[t][kk], dp, 0, 0, 0);
+        }
+        unsigned kw = 0x01010101u;
+        if (kp[t]) {
+          const unsigned char* kbp = kp[t] + j0 + key0 + 4 * qd;
+          kw = 0;
+          if (kleft >= 4) __builtin_memcpy(&kw, kbp, 4);
+          else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+              if (r < kleft) kw |= (unsigned)kbp[r] << (8 * r);
+          }
+        }
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pj = r < kleft ? __builtin_amdgcn_exp2f(st[r] - m[t]) * rl[t] : 0.f;
+          const float dpk = ((kw >> (8 * r)) & 0xffu) ? dp[r] * kscale : 0.f;
+          ds[r] = pj * (dpk - Di[t]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[s2][dt], ds[s2], acc[t][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < ABM_T; ++t) {
+    if (qi[t] < n) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * dt + 4 * qd + r;
+          if (c < dk) dq[(row0 + qi[t]) * ld + h * dk + c] = acc[t][dt][r] * inv_temp;
+        }
+      if (qd == 0) {
+        float* st = stats + (((size_t)b * H + h) * n + qi[t]) * 3;
+        st[0] = m[t];
+        st[1] = rl[t];
+        st[2] = Di[t];
+      }
+    }
+  }
+}
+
+template <int DK4, int DT>
+__global__ __launch_bounds__(512) void gen_attn_bwd_kv_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, int ld,
+                                                                   const unsigned char* __restrict__ keep, float keep_scale,
+                                                                   const float* __restrict__ go, int ldo,
+                                                                   const float* __restrict__ stats, float* __restrict__ dkk,
+                                                                   float* __restrict__ dv, int n, int H, int dk,
+                                                                   float inv_temp) {
+  constexpr int CW = DK4 * 4 > 16 * DT ? DK4 * 4 : 16 * DT;
+  __shared__ float qs[ABM_BLK * ABM_P];
+  __shared__ float gs[ABM_BLK * ABM_P];
+  __shared__ float sts[ABM_BLK * 3];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, qd = lane >> 4;
+  const size_t row0 = (size_t)b * n;
+  const float kscale = keep ? keep_scale : 1.f;   // without a mask nothing is rescaled
+  int kj[ABM_T];
+  float kreg[ABM_T][DK4], vreg[ABM_T][DK4];
+  f32x4 accK[ABM_T][DT], accV[ABM_T][DT];
+  const unsigned char* kp[ABM_T];
+#pragma unroll
+  for (int t = 0; t < ABM_T; ++t) {
+    kj[t] = blockIdx.x * (16 * ABM_T * 8) + (wave * ABM_T + t) * 16 + p;
+    const int jc = kj[t] < n ? kj[t] : n - 1;
+    const float* krow = k + (row0 + jc) * ld + h * dk;
+    const float* vrow = v + (row0 + jc) * ld + h * dk;
+#pragma unroll
+    for (int kk = 0; kk < DK4; ++kk) {
+      const int d = 4 * kk + qd;
+      kreg[t][kk] = d < dk ? krow[d] : 0.f;
+      vreg[t][kk] = d < dk ? vrow[d] : 0.f;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) accK[t][dt] = accV[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    kp[t] = keep ? keep + ((size_t)b * H + h) * n * n + jc : nullptr;
+  }
+  AbmRegs<CW> rq, rg;
+  float rs = 0.f;
+  const float* const srow = stats + ((size_t)b * H + h) * n * 3;
+  abm_fetch<CW>(rq, q, row0, ld, h * dk, 0, n, dk);
+  abm_fetch<CW>(rg, go, row0, ldo, h * dk, 0, n, dk);
+  if (threadIdx.x < ABM_BLK * 3) rs = (int)threadIdx.x / 3 < n ? srow[threadIdx.x] : 0.f;
+  for (int i0 = 0; i0 < n; i0 += ABM_BLK) {
+    __syncthreads();   // the previous block's products have read the tiles
+    abm_put<CW>(rq, qs, inv_temp);
+    abm_put<CW>(rg, gs, 1.f);
+    if (threadIdx.x < ABM_BLK * 3) sts[threadIdx.x] = rs;
+    __syncthreads();
+    if (i0 + ABM_BLK < n) {
+      const int i1 = i0 + ABM_BLK;
+      abm_fetch<CW>(rq, q, row0, ld, h * dk, i1, n, dk);
+      abm_fetch<CW>(rg, go, row0, ldo, h * dk, i1, n, dk);
+      if (threadIdx.x < ABM_BLK * 3) rs = i1 + (int)threadIdx.x / 3 < n ? srow[(size_t)i1 * 3 + threadIdx.x] : 0.f;
+    }
+    const int nqt = (min(n - i0, ABM_BLK) + 15) >> 4;
+    for (int qt = 0; qt < nqt; ++qt) {
+      const int q0 = 16 * qt;
+      float qa[DK4], ga[DK4], qb[4][DT], gb[4][DT], sm[4], srl[4], sD[4];
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk) {
+        qa[kk] = qs[(q0 + p) * ABM_P + 4 * kk + qd];
+        ga[kk] = gs[(q0 + p) * ABM_P + 4 * kk + qd];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          qb[s2][dt] = qs[(q0 + 4 * qd + s2) * ABM_P + 16 * dt + p];
+          gb[s2][dt] = gs[(q0 + 4 * qd + s2) * ABM_P + 16 * dt + p];
+        }
+        sm[s2] = sts[(q0 + 4 * qd + s2) * 3];
+        srl[s2] = sts[(q0 + 4 * qd + s2) * 3 + 1];
+        sD[s2] = sts[(q0 + 4 * qd + s2) * 3 + 2];
+      }
+      const int qleft = n - (i0 + q0 + 4 * qd);   // queries of this lane that exist
+      // the keep bytes of the lane's (query, key) pairs are requested before the products that need them
+      unsigned char kbyte[ABM_T][4];
+      if (keep) {
+#pragma unroll
+        for (int t = 0; t < ABM_T; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) kbyte[t][r] = r < qleft ? kp[t][(size_t)(i0 + q0 + 4 * qd + r) * n] : 0;
+      }
+#pragma unroll
+      for (int t = 0; t < ABM_T; ++t) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK4; ++kk) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kk], kreg[t][kk], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[kk], vreg[t][kk], dp, 0, 0, 0);
+        }
+        float pm[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pj = r < qleft ? __builtin_amdgcn_exp2f(st[r] * LOG2E - sm[r]) * srl[r] : 0.f;
+          const bool kept = keep ? kbyte[t][r] != 0 : true;
+          pm[r] = kept ? pj * kscale : 0.f;
+          const float dpk = kept ? dp[r] * kscale : 0.f;
+          ds[r] = pj * (dpk - sD[r]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            accV[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[s2][dt], pm[s2], accV[t][dt], 0, 0, 0);
+            accK[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[s2][dt], ds[s2], accK[t][dt], 0, 0, 0);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < ABM_T; ++t) {
+    if (kj[t] < n) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * dt + 4 * qd + r;
+          if (c < dk) {
+            dkk[(row0 + kj[t]) * ld + h * dk + c] = accK[t][dt][r];
+            dv[(row0 + kj[t]) * ld + h * dk + c] = accV[t][dt][r];
+          }
+        }
+    }
+  }
+}
+
 // ---- VAD head backward (models.py:601): gx[b][token 0][:] += dvad[b] * w; slab-free: one workgroup folds dw and db --------
 __global__ __launch_bounds__(256) void gen_vad_bwd_kernel(const float* __restrict__ x, float* __restrict__ gx, int ld,
                                                           long tokens_per_clip, const float* __restrict__ w,
@@ -724,6 +1064,27 @@ NOISE_EXPORT int noise_gen_attn_bwd(const float* q, const float* k, const float*
   NOISE_REQUIRE(q && k && v && o && go && dq && dk_ && dv && stats, "noise_gen_attn_bwd: null pointer");
   NOISE_REQUIRE(B > 0 && n > 0 && H > 0 && dk > 0 && dk <= 64, "noise_gen_attn_bwd: head size must be in 1..64 (got %d)", dk);
   NOISE_REQUIRE(B <= 65535 && H <= 65535 && ld >= H * dk && ldo >= H * dk && temperature > 0.f, "noise_gen_attn_bwd: bad shape");
+  hipStream_t st0 = (hipStream_t)stream;
+  // heads of at most 32 run on the matrix cores (NOISE_TOK_ATT_VALU, diagnostic: the thread-per-query / per-key kernels)
+  static const bool valu_only = getenv("NOISE_TOK_ATT_VALU") != nullptr;
+  if (dk <= 32 && !valu_only) {
+    const dim3 gm(noise_cdiv(n, 16 * ABM_T * 8), H, B);
+    const float itm = 1.f / temperature;
+#define ABM_CASE(K4, T)                                                                                                 \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((gen_attn_bwd_q_mfma_kernel<K4, T>), gm, dim3(512), 0, st0, q, k, v, ld, keep, keep_scale, o, go, ldo, \
+                       dq, stats, n, H, dk, itm);                                                                       \
+    hipLaunchKernelGGL((gen_attn_bwd_kv_mfma_kernel<K4, T>), gm, dim3(512), 0, st0, q, k, v, ld, keep, keep_scale, go, ldo,   \
+                       stats, dk_, dv, n, H, dk, itm);                                                                  \
+  } while (0)
+    if (dk <= 8) ABM_CASE(2, 1);
+    else if (dk <= 16) ABM_CASE(4, 1);
+    else if (dk <= 24) ABM_CASE(6, 2);
+    else ABM_CASE(8, 2);
+#undef ABM_CASE
+    NOISE_CHECK_LAUNCH("noise_gen_attn_bwd");
+    return 0;
+  }
   // short clips: workgroups of 64 or 128 queries / keys, so that few lanes are left without one
   const int nt = n <= 64 ? 64 : (n <= 128 ? 128 : 256);
   const dim3 grid(noise_cdiv(n, nt), H, B);

@@ -231,23 +231,37 @@ __global__ __launch_bounds__(512) void tok_attention_mfma_kernel(const float* __
     l[t] = 0.f;
     kp[t] = keep ? keep + (((size_t)b * H + h) * n + qc) * n : nullptr;
   }
-  for (int j0 = 0; j0 < n; j0 += ATM_KB) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < ATM_KB * DKP; e += 512) {
-      const int j = e / DKP, d = e - j * DKP;
+  // a block's keys and values are requested into registers while the previous block is multiplied
+  constexpr int NV = ATM_KB * DKP / 512;
+  float rk[NV], rv[NV];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + 512 * i, j = e / DKP, d = e - j * DKP;
       const bool in = j0 + j < n && d < dk;
       const size_t at = (row0 + (j0 + j < n ? j0 + j : n - 1)) * ld + h * dk + (d < dk ? d : 0);
       const float kv = k[at], vv = v[at];
-      ks[j * KP + d] = in ? kv : 0.f;
-      if (d < 16 * DT) vs[j * VP + d] = in ? vv : 0.f;
+      rk[i] = in ? kv : 0.f;
+      rv[i] = in ? vv : 0.f;
     }
-    if (DKP < 16 * DT) {   // value columns the key loop above does not reach
-      for (int e = threadIdx.x; e < ATM_KB * (16 * DT - DKP); e += 512) {
-        const int j = e / (16 * DT - DKP), d = DKP + e - j * (16 * DT - DKP);
-        vs[j * VP + d] = 0.f;
-      }
+  };
+  if (DKP < 16 * DT) {   // value columns the staging never reaches stay zero
+    for (int e = threadIdx.x; e < ATM_KB * (16 * DT - DKP); e += 512) {
+      const int j = e / (16 * DT - DKP), d = DKP + e - j * (16 * DT - DKP);
+      vs[j * VP + d] = 0.f;
+    }
+  }
+  fetch(0);
+  for (int j0 = 0; j0 < n; j0 += ATM_KB) {
+    __syncthreads();   // the previous block's products have read the tiles
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + 512 * i, j = e / DKP, d = e - j * DKP;
+      ks[j * KP + d] = rk[i];
+      if (d < 16 * DT) vs[j * VP + d] = rv[i];
     }
     __syncthreads();
+    if (j0 + ATM_KB < n) fetch(j0 + ATM_KB);
     const int nkt = (min(n - j0, ATM_KB) + 15) >> 4;
     for (int kt = 0; kt < nkt; ++kt) {
       const int key0 = 16 * kt;

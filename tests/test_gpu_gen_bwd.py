@@ -93,7 +93,9 @@ def test_ln_bwd(M, D):
     assert rel(out2, r64.grad) < 2e-5
 
 
-@pytest.mark.parametrize("B,n,H,dk,p", [(2, 250, 6, 21, 0.1), (1, 300, 4, 8, 0.0), (3, 37, 3, 32, 0.25), (1, 260, 2, 40, 0.1)])
+@pytest.mark.parametrize("B,n,H,dk,p", [(2, 250, 6, 21, 0.1), (1, 300, 4, 8, 0.0), (3, 37, 3, 32, 0.25), (1, 260, 2, 40, 0.1),
+                                         (2, 251, 6, 21, 0.0), (1, 515, 2, 16, 0.2), (1, 65, 1, 5, 0.3), (2, 16, 2, 24, 0.1),
+                                         (1, 1031, 2, 10, 0.1)])
 def test_attention_bwd(B, n, H, dk, p):
     from noise_amd import _lib, generic, generic_train  # noqa: F401  (register the entry points)
     g = torch.Generator().manual_seed(n + dk)
