@@ -736,6 +736,272 @@ __global__ __launch_bounds__(AW) void attn_core_bwd_wave_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the core for segments (n <= 64 tokens) on the matrix cores: one workgroup of four waves per (clip, head),
+// q (already divided by the temperature), k, v and dO of the head in LDS (rows of 36 floats: the 64 lanes of every
+// operand read fall on 64 banks).  The score tiles stay in the registers the fp32 MFMA leaves them in, which is the
+// operand layout of the next product:
+//   pass Q  (a wave owns a tile of 16 queries): S^T = K Q^T and dP^T = V dO^T give a lane 4 keys of one query; with
+//           w = p * dp (dropout applied) the row term D_i = sum_j w_ij needs all keys, so the pass accumulates
+//           A1 = K^T W^T and A2 = K^T P^T and forms dQ^T = A1 - D A2 at the end;
+//   pass KV (a wave owns a tile of 16 keys): S = Q K^T and dP = dO V^T give a lane 4 queries of one key;
+//           dV^T += dO^T Pk and dK^T += Q^T dS with k = the lane's own queries.
+// The softmax statistics are the forward's (ml), the keep decisions come from the same keep_at as everywhere else.
+// (The thread-per-query form spends its time on the LDS pipe: ~1100 LDS instructions per wave; 0.233 ms per step.)
+constexpr int ASG_P = 36;
+
+__device__ __forceinline__ float sum_over_quarters(float v) {   // over lanes p, p + 16, p + 32, p + 48
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(v);
+  u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float max_over_quarters(float v) {   // over lanes p, p + 16, p + 32, p + 48
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(v);
+  u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Forward of the core for segments, same arrangement: a wave owns 16 queries; S^T = K Q^T for all (at most four) key
+// tiles, the row maximum and sum as in the thread-per-query kernel (the sum runs over all keys, dropout only removes
+// terms of the numerator), then O^T += V^T P^T with k = the lane's own keys.
+template <int DK4, int DROP>
+__global__ __launch_bounds__(256) void attn_core_fwd_seg_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                     float* __restrict__ ml,
+                                                                     const unsigned char* __restrict__ keep,
+                                                                     unsigned long long seed, float p_drop, AttnDims d) {
+  __shared__ float ks[64 * ASG_P], vs[64 * ASG_P];
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int vblk = xcd_chunked_block();
+  if (vblk >= (int)(d.ntok / n) * d.heads) return;
+  const int b = vblk / d.heads, h = vblk % d.heads;
+  const long base = (long)b * n;
+  const float temp = sqrtf((float)dk);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  const long bhn = ((long)b * d.heads + h) * n;
+  for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+    const int j = e >> 4, c = e & 15;
+    const bool in = j < n && c < dk;
+    const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : 0);
+    const float kv = row[d.hd], vv = row[2 * d.hd];
+    ks[j * ASG_P + c] = in ? kv : 0.f;
+    vs[j * ASG_P + c] = in ? vv : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, qd = lane >> 4;
+  const int q0 = 16 * wave, qi = q0 + p, qc = qi < n ? qi : n - 1;
+  float qreg[DK4];
+#pragma unroll
+  for (int kk = 0; kk < DK4; ++kk) {
+    const int c = 4 * kk + qd;
+    const float v = qkv[(base + qc) * O + h * dk + (c < dk ? c : 0)] / temp;
+    qreg[kk] = c < dk ? v : 0.f;
+  }
+  __syncthreads();
+  if (q0 >= n) return;
+  const int ntile = (n + 15) >> 4;
+  f32x4 st[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kt < ntile) {
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk)
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[(16 * kt + p) * ASG_P + 4 * kk + qd], qreg[kk], st[kt], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + 4 * qd + r < n) m = fmaxf(m, st[kt][r]);
+    }
+  }
+  m = max_over_quarters(m);
+  const long mrow = (bhn + qc) * n;
+  float l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt < ntile) {
+      float pr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * qd + r;
+        const bool ok = key < n;
+        const float e = ok ? exp_hw(st[kt][r] - m) : 0.f;
+        l += e;
+        pr[r] = (ok && keep_at<DROP>(keep, seed, p_drop, mrow + (ok ? key : 0))) ? e : 0.f;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[(16 * kt + 4 * qd + s2) * ASG_P + p], pr[s2], acc, 0, 0, 0);
+    }
+  }
+  l = sum_over_quarters(l);
+  if (qi < n) {
+    const float sc = inv_keep / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * qd + r;
+      if (c < dk) o[(base + qi) * d.hd + h * dk + c] = acc[r] * sc;
+    }
+    if (ml && qd == 0) {
+      ml[(bhn + qi) * 2] = m;
+      ml[(bhn + qi) * 2 + 1] = l;
+    }
+  }
+}
+
+template <int DK4, int DROP>
+__global__ __launch_bounds__(256) void attn_core_bwd_seg_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                     const float* __restrict__ ml,
+                                                                     const unsigned char* __restrict__ keep,
+                                                                     unsigned long long seed, float p_drop,
+                                                                     float* __restrict__ d_qkv, AttnDims d) {
+  __shared__ float qs[64 * ASG_P], ks[64 * ASG_P], vs[64 * ASG_P], gs[64 * ASG_P];
+  __shared__ float sm[64], srl[64], sD[64];
+  const int n = d.n, dk = d.dk, O = 3 * d.hd;
+  const int vblk = xcd_chunked_block();      // see attn_core_fwd_wave_kernel
+  if (vblk >= (int)(d.ntok / n) * d.heads) return;
+  const int b = vblk / d.heads, h = vblk % d.heads;
+  const long base = (long)b * n;
+  const float temp = sqrtf((float)dk);
+  const float inv_keep = 1.f / (1.f - p_drop);
+  const long bhn = ((long)b * d.heads + h) * n;
+  for (int e = threadIdx.x; e < 64 * 16; e += 256) {   // 16 columns: every k-step and the one 16-wide output tile
+    const int j = e >> 4, c = e & 15;
+    const bool in = j < n && c < dk;
+    const float* row = qkv + (base + (j < n ? j : n - 1)) * O + h * dk + (c < dk ? c : 0);
+    const float qv = row[0], kv = row[d.hd], vv = row[2 * d.hd];
+    const float gv = d_o[(base + (j < n ? j : n - 1)) * d.hd + h * dk + (c < dk ? c : 0)];
+    qs[j * ASG_P + c] = in ? qv / temp : 0.f;
+    ks[j * ASG_P + c] = in ? kv : 0.f;
+    vs[j * ASG_P + c] = in ? vv : 0.f;
+    gs[j * ASG_P + c] = in ? gv : 0.f;
+  }
+  if (threadIdx.x < 64) {
+    const int j = threadIdx.x < n ? threadIdx.x : n - 1;
+    sm[threadIdx.x] = ml[(bhn + j) * 2];
+    srl[threadIdx.x] = 1.f / ml[(bhn + j) * 2 + 1];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, qd = lane >> 4;
+  const int ntile = (n + 15) >> 4;
+  // ---- pass Q
+  {
+    const int q0 = 16 * wave;
+    if (q0 < n) {
+      const int qi = q0 + p, qc = qi < n ? qi : n - 1;
+      float qreg[DK4], greg[DK4];
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk) {
+        qreg[kk] = qs[(q0 + p) * ASG_P + 4 * kk + qd];
+        greg[kk] = gs[(q0 + p) * ASG_P + 4 * kk + qd];
+      }
+      const float mi = sm[qc], li = srl[qc];
+      const long mrow = (bhn + qc) * n;
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+      float dpart = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        if (kt >= ntile) break;   // at most four tiles: unrolled so that a tile's products start under the previous tile's arithmetic
+        const int key0 = 16 * kt;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK4; ++kk) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[(key0 + p) * ASG_P + 4 * kk + qd], qreg[kk], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[(key0 + p) * ASG_P + 4 * kk + qd], greg[kk], dp, 0, 0, 0);
+        }
+        float w1[4], w2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + 4 * qd + r;
+          const bool ok = key < n;
+          const float pj = ok ? exp_hw(st[r] - mi) * li : 0.f;
+          const bool kept = ok && keep_at<DROP>(keep, seed, p_drop, mrow + (ok ? key : 0));
+          w1[r] = kept ? pj * (dp[r] * inv_keep) : 0.f;
+          w2[r] = pj;
+          dpart += w1[r];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const float kb = ks[(key0 + 4 * qd + s2) * ASG_P + p];
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb, w1[s2], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb, w2[s2], a2, 0, 0, 0);
+        }
+      }
+      const float Di = sum_over_quarters(dpart);
+      if (qi < n) {
+        float* row = d_qkv + (base + qi) * O + h * dk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * qd + r;
+          if (c < dk) row[c] = (a1[r] - Di * a2[r]) / temp;
+        }
+        if (qd == 0) sD[qi] = Di;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pass KV
+  {
+    const int key0 = 16 * wave;
+    if (key0 < n) {
+      const int kj = key0 + p;
+      const bool kok = kj < n;
+      float kreg[DK4], vreg[DK4];
+#pragma unroll
+      for (int kk = 0; kk < DK4; ++kk) {
+        kreg[kk] = ks[(key0 + p) * ASG_P + 4 * kk + qd];
+        vreg[kk] = vs[(key0 + p) * ASG_P + 4 * kk + qd];
+      }
+      f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        if (qt >= ntile) break;
+        const int q0 = 16 * qt;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK4; ++kk) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[(q0 + p) * ASG_P + 4 * kk + qd], kreg[kk], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[(q0 + p) * ASG_P + 4 * kk + qd], vreg[kk], dp, 0, 0, 0);
+        }
+        float pm[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = q0 + 4 * qd + r;
+          const bool ok = qq < n && kok;
+          const int qc = qq < n ? qq : n - 1;
+          const float pj = ok ? exp_hw(st[r] - sm[qc]) * srl[qc] : 0.f;
+          const bool kept = ok && keep_at<DROP>(keep, seed, p_drop, (bhn + qc) * n + (kok ? kj : 0));
+          pm[r] = kept ? pj * inv_keep : 0.f;
+          const float dpk = kept ? dp[r] * inv_keep : 0.f;
+          ds[r] = ok ? pj * (dpk - sD[qc]) : 0.f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          av = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[(q0 + 4 * qd + s2) * ASG_P + p], pm[s2], av, 0, 0, 0);
+          ak = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[(q0 + 4 * qd + s2) * ASG_P + p], ds[s2], ak, 0, 0, 0);
+        }
+      }
+      if (kok) {
+        float* row = d_qkv + (base + kj) * O + h * dk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * qd + r;
+          if (c < dk) {
+            row[d.hd + c] = ak[r];
+            row[2 * d.hd + c] = av[r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // B'': the core without dropout (inference, validation) for clips of any length: fp32 MFMA tiles with an online
 // softmax, so the n x n scores are never materialised and never recomputed.  K and V of one (clip, head) live in
 // LDS; a wave owns 16 queries and walks the keys 16 at a time:
@@ -1245,6 +1511,29 @@ NOISE_EXPORT int noise_attn_core_fwd(const float* qkv, float* o, float* ml, cons
   NOISE_REQUIRE(qkv && o, "noise_attn_core_fwd: null pointer");
   NOISE_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "noise_attn_core_fwd: p_drop=%f out of range", p_drop);
   AttnDims d{ntok, n, heads, dk, heads * dk};
+  // segments: fp32 MFMA tiles, four waves per (clip, head) (NOISE_ATTN_FWD_WAVE, diagnostic: the thread-per-query form)
+  static const bool wave_form = getenv("NOISE_ATTN_FWD_WAVE") != nullptr;
+  if (n <= AW && !wave_form) {
+    const int dk4 = (dk + 3) / 4;
+    const dim3 grid((unsigned)noise_pad8((ntok / n) * heads));
+    const int drop = keep ? 1 : (p_drop > 0.f ? 2 : 0);
+#define X(K4)                                                                                                     \
+  if (dk4 == K4) {                                                                                                \
+    if (drop == 0)                                                                                                \
+      hipLaunchKernelGGL((attn_core_fwd_seg_mfma_kernel<K4, 0>), grid, dim3(256), 0, (hipStream_t)stream, qkv, o, ml, keep, \
+                         seed, p_drop, d);                                                                        \
+    else if (drop == 1)                                                                                           \
+      hipLaunchKernelGGL((attn_core_fwd_seg_mfma_kernel<K4, 1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, o, ml, keep, \
+                         seed, p_drop, d);                                                                        \
+    else                                                                                                          \
+      hipLaunchKernelGGL((attn_core_fwd_seg_mfma_kernel<K4, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, o, ml, keep, \
+                         seed, p_drop, d);                                                                        \
+  }
+    X(1) X(2) X(3) X(4)
+#undef X
+    NOISE_CHECK_LAUNCH("noise_attn_core_fwd/mfma");
+    return 0;
+  }
   if (n <= AW) {   // one wave per (clip, head)
     const int dk4 = (dk + 3) / 4;
     const size_t sm = (size_t)2 * n * dk4 * 4 * sizeof(float);
@@ -1303,6 +1592,29 @@ NOISE_EXPORT int noise_attn_core_bwd(const float* qkv, const float* d_o, const f
   if (check_attn("noise_attn_core_bwd", ntok, n, d_model, heads, dk)) return -1;
   NOISE_REQUIRE(qkv && d_o && ml && d_qkv, "noise_attn_core_bwd: null pointer");
   AttnDims d{ntok, n, heads, dk, heads * dk};
+  // segments: fp32 MFMA tiles, four waves per (clip, head) (NOISE_ATTN_BWD_WAVE, diagnostic: the thread-per-query form)
+  static const bool wave_form = getenv("NOISE_ATTN_BWD_WAVE") != nullptr;
+  if (n <= AW && !wave_form) {
+    const int dk4 = (dk + 3) / 4;
+    const dim3 grid((unsigned)noise_pad8((ntok / n) * heads));
+    const int drop = keep ? 1 : (p_drop > 0.f ? 2 : 0);
+#define X(K4)                                                                                                        \
+  if (dk4 == K4) {                                                                                                   \
+    if (drop == 0)                                                                                                   \
+      hipLaunchKernelGGL((attn_core_bwd_seg_mfma_kernel<K4, 0>), grid, dim3(256), 0, (hipStream_t)stream, qkv, d_o, ml, keep, \
+                         seed, p_drop, d_qkv, d);                                                                    \
+    else if (drop == 1)                                                                                              \
+      hipLaunchKernelGGL((attn_core_bwd_seg_mfma_kernel<K4, 1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, d_o, ml, keep, \
+                         seed, p_drop, d_qkv, d);                                                                    \
+    else                                                                                                             \
+      hipLaunchKernelGGL((attn_core_bwd_seg_mfma_kernel<K4, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, d_o, ml, keep, \
+                         seed, p_drop, d_qkv, d);                                                                    \
+  }
+    X(1) X(2) X(3) X(4)
+#undef X
+    NOISE_CHECK_LAUNCH("noise_attn_core_bwd/mfma");
+    return 0;
+  }
   if (n <= AW) {   // one wave per (clip, head)
     const int dk4 = (dk + 3) / 4;
     const size_t sm = (size_t)(4 * n * dk4 * 4 + n * (n | 1)) * sizeof(float);
