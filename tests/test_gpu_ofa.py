@@ -75,7 +75,10 @@ def test_layers_against_torch():
         torch.testing.assert_close(coef[3 * C:4 * C].double(), 1 / torch.sqrt(flat.var(0, unbiased=False) + 1e-5), rtol=1e-3, atol=1e-5)
 
     # 1x1 with sliced weights and a lazily normalised source
-    for npix, K, N, Kmax, Nmax in ((1000, 24, 144, 24, 144), (333, 136, 40, 192, 48), (70, 1152, 200, 1920, 320), (64, 8, 8, 16, 8)):
+    # (the widths cover every channel-tile count of the kernel, the long one a grid cut to whole rounds)
+    for npix, K, N, Kmax, Nmax in ((1000, 24, 144, 24, 144), (333, 136, 40, 192, 48), (70, 1152, 200, 1920, 320), (64, 8, 8, 16, 8),
+                                   (300000, 32, 96, 32, 96), (5000, 64, 576, 64, 576), (2000, 48, 24, 48, 24),
+                                   (2000, 32, 16, 32, 16), (90000, 16, 128, 16, 128)):
         a = torch.randn(npix, K, device=dev, generator=g)
         W = torch.randn(Nmax, Kmax, 1, 1, device=dev, generator=g) / K ** 0.5
         coef = torch.cat([torch.rand(K, device=dev, generator=g) + 0.5, torch.randn(K, device=dev, generator=g)])
