@@ -160,6 +160,74 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(LazyGrad G, LazySrc A, Lazy
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of a stride-2 transposed layer on one-row tensors (B rows of Wi pixels -> Wo = 2 Wi - 1; the 1 x 3 kernel is
+// the middle row of the 3 x 3 one).  The column walkers have a single row to walk there and the per-pixel kernel reads
+// six gradient vectors per input pixel; here a thread owns 4 channels of NPX consecutive input pixels: it loads their
+// NPX + 2 inputs and 2 NPX + 1 output gradients once, rebuilds the raw layer output the lazy gradient needs from the
+// inputs (even column 2x: a[x] w1; odd column 2x + 1: a[x + 1] w0, then a[x] w2 -- the forward's order), and applies the
+// producer's epilogue.  The workgroup has PPB * C/4 threads (every lane has a channel quad); slab rows as dw_bwd_kernel.
+template <int NPX>
+__global__ __launch_bounds__(512) void dw_row_t2_bwd_kernel(LazyGrad G, LazySrc A, const float* __restrict__ w,
+                                                            float* __restrict__ g_in, float* __restrict__ dw_slab,
+                                                            BwdEpilogue E, int B, int Wi, int C, int PPB) {
+  extern __shared__ float red[];
+  const int CG = C >> 2;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  const Lazy4 a = lazy4_init(A, C, c);
+  const LazyGrad4 g = lazygrad4_init(G, C, c);
+  const Epi4 epi = epi4_init(E, C, c);
+  float4 wk[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wk[k] = make_float4(w[(c + 0) * 9 + 3 + k], w[(c + 1) * 9 + 3 + k], w[(c + 2) * 9 + 3 + k], w[(c + 3) * 9 + 3 + k]);
+  float4 dwk[3] = {f4(0.f), f4(0.f), f4(0.f)}, s1 = f4(0.f), s2 = f4(0.f);
+  const int Wo = 2 * Wi - 1, GX = (Wi + NPX - 1) / NPX;
+  int g0, g1;
+  pixel_chunk(B * GX, PPB, g0, g1);
+  for (int grp = g0 + pl; grp < g1; grp += PPB) {
+    const int b = grp / GX, x0 = (grp - b * GX) * NPX;
+    // inputs x0 - 1 .. x0 + NPX (raw and activated; zero where the pixel does not exist)
+    float4 araw[NPX + 2], av[NPX + 2];
+#pragma unroll
+    for (int u = 0; u < NPX + 2; ++u) {
+      const int ix = x0 - 1 + u;
+      const bool ok = ix >= 0 && ix < Wi;
+      araw[u] = ld4(a.y + ((size_t)b * Wi + (ok ? ix : 0)) * C + c);
+      const float4 v = lazy4_act(a, araw[u]);
+      av[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    // output gradients at columns 2 x0 - 1 .. 2 x0 + 2 NPX - 1
+    float4 dy[2 * NPX + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * NPX + 1; ++j) {
+      const int ox = 2 * x0 - 1 + j;
+      const bool ok = ox >= 0 && ox < Wo;
+      const float4 dz = ld4(g.dz + ((size_t)b * Wo + (ok ? ox : 0)) * C + c);
+      // j odd: even column 2 (x0 + (j - 1) / 2); j even: odd column 2 x + 1 with x = x0 + j / 2 - 1
+      const float4 y = (j & 1) ? av[(j - 1) / 2 + 1] * wk[1] : fma4(av[j / 2], wk[2], av[j / 2 + 1] * wk[0]);
+      const float4 v = lazygrad4_eval(g, dz, y);
+      dy[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      const int ix = x0 + u;
+      if (ix < Wi) {
+        float4 acc = f4(0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          acc = fma4(dy[2 * u + k], wk[k], acc);
+          dwk[k] = fma4(dy[2 * u + k], av[u + 1], dwk[k]);
+        }
+        const size_t ioff = ((size_t)b * Wi + ix) * C + c;
+        acc = epi4_apply(epi, acc, araw[u + 1], ioff, s1, s2);
+        if (g_in != nullptr) st4(g_in + ioff, acc);
+      }
+    }
+  }
+  const float4 v[11] = {f4(0.f), f4(0.f), f4(0.f), dwk[0], dwk[1], dwk[2], f4(0.f), f4(0.f), f4(0.f), s1, s2};
+  block_channel_reduce<11>(v, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
+}
+
+// ------------------------------------------------------------------------------------------------
 // first layer: single-channel input, normalised by its per-clip max and padded on the fly.
 //   x_in(b, py, px) = pad_value if py < hp or px < wp else logmag[b][py-hp][px-wp] / (absmax[b] + 1e-6)
 struct FirstDims {
@@ -662,6 +730,30 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   } else {
     grid = conv_grid((long)B * Hi * Wi, C);
     // the adjoint of a CONV gather is a CONVT gather and vice versa
+    static const bool row_off = getenv("NOISE_DW_NO_ROW_KERNEL") != nullptr;   // diagnostic
+    if (transposed && Hi == 1 && sx == 2 && b_y == nullptr && !row_off) {
+      // one-row tensors: a thread takes 4 consecutive pixels; the workgroup is as many whole pixel lanes as 512 threads
+      // and 64 KB of reduction space hold
+      const int CG = C / 4;
+      int ppb = 512 / CG;
+      const int lds_cap = (int)(65536 / ((size_t)11 * C * sizeof(float)));
+      if (ppb > lds_cap) ppb = lds_cap;
+      if (ppb >= 1) {
+        constexpr int NPX = 4;
+        const long groups = (long)B * ((Wi + NPX - 1) / NPX);
+        grid = noise_grid(groups, ppb * 2, 1024);
+        const size_t sm = (size_t)ppb * 11 * C * sizeof(float);
+        NOISE_ALLOW_LDS(dw_row_t2_bwd_kernel<NPX>, sm);
+        hipLaunchKernelGGL(dw_row_t2_bwd_kernel<NPX>, dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);
+        if (slab_rows) *slab_rows = grid;
+        NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/row");
+        if (dw != nullptr) {
+          hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
+          NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
+        }
+        return 0;
+      }
+    }
     if (transposed)
       hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
     else
