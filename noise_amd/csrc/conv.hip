@@ -227,6 +227,70 @@ __global__ __launch_bounds__(512) void dw_row_t2_bwd_kernel(LazyGrad G, LazySrc 
   block_channel_reduce<11>(v, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
 }
 
+// The same for a plain stride-2 layer on one-row tensors (Wi -> Wo = (Wi - 1) / 2 + 1): a thread owns 4 channels of NOX
+// output pixels = 2 NOX input pixels.  Input 2m receives dy[m] w1, input 2m + 1 receives dy[m + 1] w0, then dy[m] w2; the raw
+// layer output of the lazy gradient is rebuilt as a[2o - 1] w0, a[2o] w1, a[2o + 1] w2 in that order (the forward's).
+template <int NOX>
+__global__ __launch_bounds__(512) void dw_row_c2_bwd_kernel(LazyGrad G, LazySrc A, const float* __restrict__ w,
+                                                            float* __restrict__ g_in, float* __restrict__ dw_slab,
+                                                            BwdEpilogue E, int B, int Wi, int C, int PPB) {
+  extern __shared__ float red[];
+  const int CG = C >> 2;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  const Lazy4 a = lazy4_init(A, C, c);
+  const LazyGrad4 g = lazygrad4_init(G, C, c);
+  const Epi4 epi = epi4_init(E, C, c);
+  float4 wk[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wk[k] = make_float4(w[(c + 0) * 9 + 3 + k], w[(c + 1) * 9 + 3 + k], w[(c + 2) * 9 + 3 + k], w[(c + 3) * 9 + 3 + k]);
+  float4 dwk[3] = {f4(0.f), f4(0.f), f4(0.f)}, s1 = f4(0.f), s2 = f4(0.f);
+  const int Wo = (Wi - 1) / 2 + 1, GX = (Wo + NOX - 1) / NOX;
+  int g0, g1;
+  pixel_chunk(B * GX, PPB, g0, g1);
+  for (int grp = g0 + pl; grp < g1; grp += PPB) {
+    const int b = grp / GX, o0 = (grp - b * GX) * NOX;
+    // inputs 2 o0 - 1 .. 2 o0 + 2 NOX + 1 (raw and activated; zero where the pixel does not exist)
+    float4 araw[2 * NOX + 3], av[2 * NOX + 3];
+#pragma unroll
+    for (int u = 0; u < 2 * NOX + 3; ++u) {
+      const int ix = 2 * o0 - 1 + u;
+      const bool ok = ix >= 0 && ix < Wi;
+      araw[u] = ld4(a.y + ((size_t)b * Wi + (ok ? ix : 0)) * C + c);
+      const float4 v = lazy4_act(a, araw[u]);
+      av[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    // output gradients o0 .. o0 + NOX (the last one only feeds the odd input before it)
+    float4 dy[NOX + 1];
+#pragma unroll
+    for (int j = 0; j < NOX + 1; ++j) {
+      const int ox = o0 + j;
+      const bool ok = ox < Wo;
+      const float4 dz = ld4(g.dz + ((size_t)b * Wo + (ok ? ox : 0)) * C + c);
+      float4 y = av[2 * j] * wk[0];
+      y = fma4(av[2 * j + 1], wk[1], y);
+      y = fma4(av[2 * j + 2], wk[2], y);
+      const float4 v = lazygrad4_eval(g, dz, y);
+      dy[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NOX; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dwk[k] = fma4(dy[j], av[2 * j + k], dwk[k]);
+#pragma unroll
+    for (int u = 0; u < 2 * NOX; ++u) {
+      const int ix = 2 * o0 + u;
+      if (ix < Wi) {
+        const float4 acc = (u & 1) ? fma4(dy[u / 2], wk[2], dy[u / 2 + 1] * wk[0]) : dy[u / 2] * wk[1];
+        const size_t ioff = ((size_t)b * Wi + ix) * C + c;
+        const float4 o = epi4_apply(epi, acc, araw[u + 1], ioff, s1, s2);
+        if (g_in != nullptr) st4(g_in + ioff, o);
+      }
+    }
+  }
+  const float4 v[11] = {f4(0.f), f4(0.f), f4(0.f), dwk[0], dwk[1], dwk[2], f4(0.f), f4(0.f), f4(0.f), s1, s2};
+  block_channel_reduce<11>(v, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
+}
+
 // ------------------------------------------------------------------------------------------------
 // first layer: single-channel input, normalised by its per-clip max and padded on the fly.
 //   x_in(b, py, px) = pad_value if py < hp or px < wp else logmag[b][py-hp][px-wp] / (absmax[b] + 1e-6)
@@ -731,7 +795,7 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
     grid = conv_grid((long)B * Hi * Wi, C);
     // the adjoint of a CONV gather is a CONVT gather and vice versa
     static const bool row_off = getenv("NOISE_DW_NO_ROW_KERNEL") != nullptr;   // diagnostic
-    if (transposed && Hi == 1 && sx == 2 && b_y == nullptr && !row_off) {
+    if (Hi == 1 && sx == 2 && b_y == nullptr && !row_off) {
       // one-row tensors: a thread takes 4 consecutive pixels; the workgroup is as many whole pixel lanes as 512 threads
       // and 64 KB of reduction space hold
       const int CG = C / 4;
@@ -739,12 +803,17 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
       const int lds_cap = (int)(65536 / ((size_t)11 * C * sizeof(float)));
       if (ppb > lds_cap) ppb = lds_cap;
       if (ppb >= 1) {
-        constexpr int NPX = 4;
-        const long groups = (long)B * ((Wi + NPX - 1) / NPX);
+        constexpr int NPX = 4, NOX = 2;   // input pixels per thread, transposed / plain
+        const long groups = transposed ? (long)B * ((Wi + NPX - 1) / NPX) : (long)B * ((d.Wo + NOX - 1) / NOX);
         grid = noise_grid(groups, ppb * 2, 1024);
         const size_t sm = (size_t)ppb * 11 * C * sizeof(float);
-        NOISE_ALLOW_LDS(dw_row_t2_bwd_kernel<NPX>, sm);
-        hipLaunchKernelGGL(dw_row_t2_bwd_kernel<NPX>, dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);
+        if (transposed) {
+          NOISE_ALLOW_LDS(dw_row_t2_bwd_kernel<NPX>, sm);
+          hipLaunchKernelGGL(dw_row_t2_bwd_kernel<NPX>, dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);
+        } else {
+          NOISE_ALLOW_LDS(dw_row_c2_bwd_kernel<NOX>, sm);
+          hipLaunchKernelGGL(dw_row_c2_bwd_kernel<NOX>, dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);
+        }
         if (slab_rows) *slab_rows = grid;
         NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/row");
         if (dw != nullptr) {

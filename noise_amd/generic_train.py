@@ -199,10 +199,10 @@ class GenericTrain(GenericForward):
             rows_as_image = Hi == 1 and s == 1 and conv2.kernel_size[0] == 1 and os.environ.get("NOISE_GEN_ROWS") != "0"
             Bk, Hk = (1, B) if rows_as_image else (B, Hi)
             epi = (exp[3], True) if exp is not None else None
-            # a stride-2 transposed layer on one-row tensors: the 2-D column walkers have one row to walk; the per-pixel
-            # kernel (unequal strides select it; the row stride is immaterial with one row) is faster there (4 layers of
-            # the waveform network: 10.4 -> 9.2 ms), while the plain stride-2 layers stay with the walkers (1.6 vs 2.5 ms)
-            strides = (1, s) if (Hi == 1 and s == 2 and tr) else (s, s)
+            # stride-2 layers on one-row tensors: the 2-D column walkers would have a single row to walk; unequal strides
+            # select the one-row kernels (the row stride is immaterial with one row), which take several consecutive
+            # pixels per thread and rebuild the layer's raw output instead of reading it
+            strides = (1, s) if (Hi == 1 and s == 2) else (s, s)
             rows = ops.dw3x3_bwd(g2, src, None, w9, ga1, dw9, self.scratch, tr, Bk, Hk, Wi, C, strides, None, epi)
             self.grads[conv2.weight] = self._dw_grad(conv2, dw9)
             if exp is not None:

@@ -78,6 +78,15 @@ def slab_stats(slab, rows, C):
     (32, (1, 1), False, False, (4, 81, 33)),
     (72, (2, 2), True, False, (4, 41, 17)),
     (192, (2, 2), True, False, (4, 11, 5)),
+    # one-row tensors with a column stride of 2: the one-row backward kernels (several pixels per thread, the layer
+    # output rebuilt from the input), odd and even widths, channel counts that leave lanes of a 256-thread block idle
+    (48, (1, 2), True, False, (3, 1, 37)),
+    (48, (1, 2), False, False, (3, 1, 37)),
+    (24, (1, 2), False, False, (2, 1, 8)),
+    (576, (1, 2), True, False, (2, 1, 18)),
+    (576, (1, 2), False, False, (2, 1, 19)),
+    (768, (1, 2), True, False, (2, 1, 9)),
+    (16, (1, 2), True, False, (5, 1, 1)),
 ])
 def test_depthwise(dev, C, stride, transposed, two_src, shape):
     from noise_amd import ops
