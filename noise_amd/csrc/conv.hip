@@ -291,6 +291,71 @@ __global__ __launch_bounds__(512) void dw_row_c2_bwd_kernel(LazyGrad G, LazySrc 
   block_channel_reduce<11>(v, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
 }
 
+// Stride 1 on one-row tensors, plain (TR = false: out[o] = sum_k a[o - 1 + k] w[k]) or transposed (out[o] = sum_k
+// a[o + 1 - k] w[k]): a thread owns 4 channels of NPX consecutive pixels.  The column walkers serve these layers as one
+// image of B rows, but their 256-thread blocks leave lanes without a channel quad at 576 / 768 channels, and they read
+// the raw output this kernel rebuilds (ascending source index, the forward's order).
+template <bool TR, int NPX>
+__global__ __launch_bounds__(512) void dw_row_s1_bwd_kernel(LazyGrad G, LazySrc A, const float* __restrict__ w,
+                                                            float* __restrict__ g_in, float* __restrict__ dw_slab,
+                                                            BwdEpilogue E, int B, int Wi, int C, int PPB) {
+  extern __shared__ float red[];
+  const int CG = C >> 2;
+  const int tid = threadIdx.x, pl = tid / CG, cg = tid - pl * CG, c = 4 * cg;
+  const Lazy4 a = lazy4_init(A, C, c);
+  const LazyGrad4 g = lazygrad4_init(G, C, c);
+  const Epi4 epi = epi4_init(E, C, c);
+  float4 wk[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wk[k] = make_float4(w[(c + 0) * 9 + 3 + k], w[(c + 1) * 9 + 3 + k], w[(c + 2) * 9 + 3 + k], w[(c + 3) * 9 + 3 + k]);
+  const float4 wlo = TR ? wk[2] : wk[0], whi = TR ? wk[0] : wk[2];   // weights of the sources o - 1 and o + 1
+  float4 dwk[3] = {f4(0.f), f4(0.f), f4(0.f)}, s1 = f4(0.f), s2 = f4(0.f);
+  const int GX = (Wi + NPX - 1) / NPX;
+  int g0, g1;
+  pixel_chunk(B * GX, PPB, g0, g1);
+  for (int grp = g0 + pl; grp < g1; grp += PPB) {
+    const int b = grp / GX, x0 = (grp - b * GX) * NPX;
+    float4 araw[NPX + 4], av[NPX + 4];   // pixels x0 - 2 .. x0 + NPX + 1
+#pragma unroll
+    for (int u = 0; u < NPX + 4; ++u) {
+      const int ix = x0 - 2 + u;
+      const bool ok = ix >= 0 && ix < Wi;
+      araw[u] = ld4(a.y + ((size_t)b * Wi + (ok ? ix : 0)) * C + c);
+      const float4 v = lazy4_act(a, araw[u]);
+      av[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    float4 dy[NPX + 2];                   // output pixels x0 - 1 .. x0 + NPX
+#pragma unroll
+    for (int j = 0; j < NPX + 2; ++j) {
+      const int ox = x0 - 1 + j;
+      const bool ok = ox >= 0 && ox < Wi;
+      const float4 dz = ld4(g.dz + ((size_t)b * Wi + (ok ? ox : 0)) * C + c);
+      float4 y = av[j] * wlo;
+      y = fma4(av[j + 1], wk[1], y);
+      y = fma4(av[j + 2], whi, y);
+      const float4 v = lazygrad4_eval(g, dz, y);
+      dy[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      const int ix = x0 + u;
+      if (ix < Wi) {
+        float4 acc = f4(0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          acc = fma4(TR ? dy[u + k] : dy[u + 2 - k], wk[k], acc);
+          dwk[k] = TR ? fma4(dy[u + k], av[u + 2], dwk[k]) : fma4(dy[u + 1], av[u + 1 + k], dwk[k]);
+        }
+        const size_t ioff = ((size_t)b * Wi + ix) * C + c;
+        acc = epi4_apply(epi, acc, araw[u + 2], ioff, s1, s2);
+        if (g_in != nullptr) st4(g_in + ioff, acc);
+      }
+    }
+  }
+  const float4 v[11] = {f4(0.f), f4(0.f), f4(0.f), dwk[0], dwk[1], dwk[2], f4(0.f), f4(0.f), f4(0.f), s1, s2};
+  block_channel_reduce<11>(v, C, CG, PPB, red, dw_slab + (size_t)blockIdx.x * 11 * C);
+}
+
 // ------------------------------------------------------------------------------------------------
 // first layer: single-channel input, normalised by its per-clip max and padded on the fly.
 //   x_in(b, py, px) = pad_value if py < hp or px < wp else logmag[b][py-hp][px-wp] / (absmax[b] + 1e-6)
@@ -747,6 +812,39 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   const size_t smem = (size_t)(PPB * 11 > BT_ROWS ? PPB * 11 : BT_ROWS) * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   BwdEpilogue E{g_other, epi_coef, epi_relu6, nullptr};
+  // One-row tensors (NOISE_DW_NO_ROW_KERNEL, diagnostic: the general kernels): a thread takes several consecutive pixels
+  // and the layer's raw output is rebuilt from the input; the workgroup is as many whole pixel lanes as 512 threads and
+  // 64 KB of reduction space hold.  Selected by a column stride of 2 with a different row stride, or by stride 1.
+  static const bool row_off = getenv("NOISE_DW_NO_ROW_KERNEL") != nullptr;
+  if (Hi == 1 && b_y == nullptr && !row_off && ((sx == 2 && sy != sx) || (sx == 1 && sy == 1))) {
+    const int CG = C / 4;
+    int ppb = 512 / CG;
+    const int lds_cap = (int)(65536 / ((size_t)11 * C * sizeof(float)));
+    if (ppb > lds_cap) ppb = lds_cap;
+    if (ppb >= 1) {
+      constexpr int NPX = 4, NOX = 2;   // pixels per thread: input pixels (transposed, stride 1), output pixels (plain stride 2)
+      const long groups = (sx == 2 && !transposed) ? (long)B * ((d.Wo + NOX - 1) / NOX) : (long)B * ((Wi + NPX - 1) / NPX);
+      int grid = noise_grid(groups, ppb * 2, 1024);
+      const size_t sm = (size_t)ppb * 11 * C * sizeof(float);
+#define ROW_LAUNCH(...)                                                                                                 \
+  do {                                                                                                                  \
+    NOISE_ALLOW_LDS((__VA_ARGS__), sm);                                                                                 \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);    \
+  } while (0)
+      if (sx == 2 && transposed) ROW_LAUNCH(dw_row_t2_bwd_kernel<NPX>);
+      else if (sx == 2) ROW_LAUNCH(dw_row_c2_bwd_kernel<NOX>);
+      else if (transposed) ROW_LAUNCH(dw_row_s1_bwd_kernel<true, NPX>);
+      else ROW_LAUNCH(dw_row_s1_bwd_kernel<false, NPX>);
+#undef ROW_LAUNCH
+      if (slab_rows) *slab_rows = grid;
+      NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/row");
+      if (dw != nullptr) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
+        NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
+      }
+      return 0;
+    }
+  }
   int grid;
   if (sy == sx) {
     // source of the walk = dy (the layer's output size), destination = the layer's input
@@ -794,35 +892,6 @@ NOISE_EXPORT int noise_dw3x3_bwd(const float* dz, const float* y_out, const floa
   } else {
     grid = conv_grid((long)B * Hi * Wi, C);
     // the adjoint of a CONV gather is a CONVT gather and vice versa
-    static const bool row_off = getenv("NOISE_DW_NO_ROW_KERNEL") != nullptr;   // diagnostic
-    if (Hi == 1 && sx == 2 && b_y == nullptr && !row_off) {
-      // one-row tensors: a thread takes 4 consecutive pixels; the workgroup is as many whole pixel lanes as 512 threads
-      // and 64 KB of reduction space hold
-      const int CG = C / 4;
-      int ppb = 512 / CG;
-      const int lds_cap = (int)(65536 / ((size_t)11 * C * sizeof(float)));
-      if (ppb > lds_cap) ppb = lds_cap;
-      if (ppb >= 1) {
-        constexpr int NPX = 4, NOX = 2;   // input pixels per thread, transposed / plain
-        const long groups = transposed ? (long)B * ((Wi + NPX - 1) / NPX) : (long)B * ((d.Wo + NOX - 1) / NOX);
-        grid = noise_grid(groups, ppb * 2, 1024);
-        const size_t sm = (size_t)ppb * 11 * C * sizeof(float);
-        if (transposed) {
-          NOISE_ALLOW_LDS(dw_row_t2_bwd_kernel<NPX>, sm);
-          hipLaunchKernelGGL(dw_row_t2_bwd_kernel<NPX>, dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);
-        } else {
-          NOISE_ALLOW_LDS(dw_row_c2_bwd_kernel<NOX>, sm);
-          hipLaunchKernelGGL(dw_row_c2_bwd_kernel<NOX>, dim3(grid), dim3(ppb * CG), sm, st, G, A, w, g_in, scratch, E, B, Wi, C, ppb);
-        }
-        if (slab_rows) *slab_rows = grid;
-        NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/row");
-        if (dw != nullptr) {
-          hipLaunchKernelGGL(slab_reduce_kernel, dim3(noise_cdiv(9 * C, SLAB_COLS)), dim3(256), 0, st, scratch, grid, 9 * C, 11 * C, dw, 9, C, 0);
-          NOISE_CHECK_LAUNCH("noise_dw3x3_bwd/reduce");
-        }
-        return 0;
-      }
-    }
     if (transposed)
       hipLaunchKernelGGL(dw_bwd_kernel<GEOM_CONV>, dim3(grid), dim3(256), smem, st, G, A, Bs, w, g_in, scratch, E, d);
     else

@@ -194,14 +194,15 @@ class GenericTrain(GenericForward):
             s = self._stride(conv2, Hi)
             w9 = _taps3x3(conv2, False).contiguous()
             ga1, dw9 = self.new(B, Hi, Wi, C), self.new(C, 3, 3)
-            # a one-row kernel couples no rows, so a batch of one-row tensors is one image of B rows to it (the other two
-            # rows of the embedded 3x3 kernel are zero): the stride-1 column walkers then walk B rows instead of one
-            rows_as_image = Hi == 1 and s == 1 and conv2.kernel_size[0] == 1 and os.environ.get("NOISE_GEN_ROWS") != "0"
+            # One-row tensors go to the one-row kernels of noise_dw3x3_bwd (several consecutive pixels per thread, the
+            # layer's raw output rebuilt from the input): stride 1 as it is, stride 2 through unequal strides (the row
+            # stride is immaterial with one row).  NOISE_GEN_ROWS=1 (diagnostic) hands a stride-1 layer to the 2-D column
+            # walkers as ONE image of B rows instead -- a 1 x 3 kernel couples no rows and the other two rows of the
+            # embedded 3 x 3 kernel are zero -- which measures slower (23.7 against 21.7 ms per step of the waveform
+            # network).
+            rows_as_image = Hi == 1 and s == 1 and conv2.kernel_size[0] == 1 and os.environ.get("NOISE_GEN_ROWS") == "1"
             Bk, Hk = (1, B) if rows_as_image else (B, Hi)
             epi = (exp[3], True) if exp is not None else None
-            # stride-2 layers on one-row tensors: the 2-D column walkers would have a single row to walk; unequal strides
-            # select the one-row kernels (the row stride is immaterial with one row), which take several consecutive
-            # pixels per thread and rebuild the layer's raw output instead of reading it
             strides = (1, s) if (Hi == 1 and s == 2) else (s, s)
             rows = ops.dw3x3_bwd(g2, src, None, w9, ga1, dw9, self.scratch, tr, Bk, Hk, Wi, C, strides, None, epi)
             self.grads[conv2.weight] = self._dw_grad(conv2, dw9)

@@ -105,8 +105,10 @@ def dw3x3_bwd(grad, a, b, w, g_in, dw, scratch, transposed, B, Hi, Wi, C, stride
     BatchNorm-backward sums are in scratch columns [9C, 11C) of rows that are 11*C floats long."""
     dz, y, coef3 = grad
     rows = ctypes.c_int(0)
-    # stride-2 transposed layers recompute their raw output from the (4x smaller) input instead of reading it back
-    reads_y = coef3 is not None and not (transposed and tuple(stride) == (2, 2))
+    # stride-2 transposed layers recompute their raw output from the (4x smaller) input instead of reading it back, and so
+    # do the one-row kernels (one-row tensor, one source, stride 1 or a column stride of 2 with another row stride)
+    one_row = Hi == 1 and b is None and (tuple(stride) == (1, 1) or (stride[1] == 2 and stride[0] != 2))
+    reads_y = coef3 is not None and not (transposed and tuple(stride) == (2, 2)) and not one_row
     _lib.call("noise_dw3x3_bwd", ptr(dz), ptr(y), ptr(coef3), *_src(a), *_src(b), ptr(w), ptr(g_in), ptr(dw),
               ptr(scratch), ptr(g_other), *_epi(epi), ctypes.byref(rows), int(transposed), B, Hi, Wi, C, stride[0],
               stride[1], _lib.stream(),

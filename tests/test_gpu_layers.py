@@ -87,6 +87,10 @@ def slab_stats(slab, rows, C):
     (576, (1, 2), False, False, (2, 1, 19)),
     (768, (1, 2), True, False, (2, 1, 9)),
     (16, (1, 2), True, False, (5, 1, 1)),
+    (48, (1, 1), True, False, (3, 1, 37)),
+    (48, (1, 1), False, False, (3, 1, 38)),
+    (576, (1, 1), False, False, (2, 1, 19)),
+    (768, (1, 1), True, False, (2, 1, 3)),
 ])
 def test_depthwise(dev, C, stride, transposed, two_src, shape):
     from noise_amd import ops
