@@ -191,7 +191,7 @@ class GenericForward:
                 if tuple(keep.shape) != (B, Hh, n, n):
                     raise ValueError(f"attention keep mask {tuple(keep.shape)}, expected {(B, Hh, n, n)}")
             elif p > 0.0:
-                keep = (torch.rand(B, Hh, n, n, device=self.dev) >= p).to(torch.uint8)
+                keep = torch.empty(B, Hh, n, n, device=self.dev, dtype=torch.uint8).bernoulli_(1.0 - p)   # one byte per weight, no float pass
             o = torch.zeros(B * n, HDp, device=self.dev)
             base = qkv.data_ptr()
             _lib.call("noise_tok_attention", ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * HDp),

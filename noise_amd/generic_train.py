@@ -242,7 +242,7 @@ class GenericTrain(GenericForward):
                 if tuple(keep.shape) != (B, Hh, n, n):
                     raise ValueError(f"attention keep mask {tuple(keep.shape)}, expected {(B, Hh, n, n)}")
             elif p > 0.0:
-                keep = (torch.rand(B, Hh, n, n, device=self.dev) >= p).to(torch.uint8)
+                keep = torch.empty(B, Hh, n, n, device=self.dev, dtype=torch.uint8).bernoulli_(1.0 - p)   # one byte per weight, no float pass
             ks = 1.0 / (1.0 - p) if keep is not None else 1.0
             o = torch.zeros(M, HDp, device=self.dev)
             base = qkv.data_ptr()
