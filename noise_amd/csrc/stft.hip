@@ -79,22 +79,55 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 4 : 1)) void stft_frames_kernel(
   int rtc[NT];
 #pragma unroll
   for (int r = 0; r < NT; ++r) rtc[r] = 32 * (wave + 4 * r < nRT ? wave + 4 * r : nRT - 1);
-  for (int c = 0; c < R; ++c) {
-#pragma unroll 8
-    for (int kq = 0; kq < hop; kq += 2) {
-      const int kk = c * hop + kq + h;
-      const float b0 = lds[nc0 * pitch + kk + c];
-      const float b1 = lds[nc1 * pitch + kk + c];
-      const float* arow = bas + (size_t)kk * d.Rpad;
-#pragma unroll
-      for (int r = 0; r < NT; ++r) {
-        // branch-free: a wave without an r-th row tile recomputes its last one (discarded in the epilogue), so the
-        // basis loads of later steps can be issued ahead of the MFMAs of this one
-        const float a = arow[rtc[r]];
-        acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[r][0], 0, 0, 0);
-        acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[r][1], 0, 0, 0);
-      }
+  // k runs in steps of two rows (kk = 2s + h) in the order of the reference's conv1d; the operands of step s+1 (basis
+  // values from L2, samples from LDS) are requested before the MFMAs of step s, so their latency overlaps 2*NT MFMAs
+  // of this wave and those of the other resident waves instead of stalling every step
+  const int steps = n_fft >> 1;
+  const float* ap = bas + (size_t)h * d.Rpad;
+  const size_t astep = (size_t)2 * d.Rpad;
+  int l0 = nc0 * pitch + h, l1 = nc1 * pitch + h;   // sample kk of the lane's two frames: +2 per step, +1 per hop crossed
+  int into = 0;
+  (void)R;
+  auto advance = [&]() {
+    ap += astep;
+    into += 2;
+    l0 += 2;
+    l1 += 2;
+    if (into == hop) {
+      into = 0;
+      ++l0;
+      ++l1;
     }
+  };
+  // branch-free over r: a wave without an r-th row tile recomputes its last one (discarded in the epilogue)
+  auto fetch = [&](float (&a)[NT], float& b0, float& b1) {
+#pragma unroll
+    for (int r = 0; r < NT; ++r) a[r] = ap[rtc[r]];
+    b0 = lds[l0];
+    b1 = lds[l1];
+  };
+  auto mma = [&](const float (&a)[NT], float b0, float b1) {
+#pragma unroll
+    for (int r = 0; r < NT; ++r) {
+      acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0, acc[r][0], 0, 0, 0);
+      acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1, acc[r][1], 0, 0, 0);
+    }
+  };
+  // two register sets in turn (steps is even: n_fft is a multiple of 32); the scheduling barriers keep each request
+  // ahead of the MFMAs it overlaps
+  float aX[NT], aY[NT], bX0, bX1, bY0, bY1;
+  fetch(aX, bX0, bX1);
+  for (int s = 0; s < steps; s += 2) {
+    advance();
+    fetch(aY, bY0, bY1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(aX, bX0, bX1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < steps) advance();   // the last step requests itself again
+    fetch(aX, bX0, bX1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(aY, bY0, bY1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: rows are interleaved (2f = Re, 2f+1 = Im); a lane holds rows 8g+4h..+3
