@@ -22,6 +22,33 @@ struct StftDims {
 
 constexpr int STFT_TF = 64;  // frames per workgroup
 
+// Runs mma(step 0), mma(step 1), ... in order, with the operands of step j+1 (basis values from L2, samples from LDS)
+// requested before the MFMAs of step j: two operand sets in turn, and scheduling barriers so that the compiler does not
+// rotate the loop back into load -> wait -> MFMA.  fetch(j, ops) must accept a repeated last step.
+template <class Ops, class Fetch, class Mma>
+__device__ __forceinline__ void pipelined_steps(int steps, Fetch fetch, Mma mma) {
+  Ops X, Y;
+  fetch(0, X);
+  int j = 0;
+  for (; j + 1 < steps; j += 2) {
+    fetch(j + 1, Y);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(X);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(min(j + 2, steps - 1), X);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(Y);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (j < steps) mma(X);
+}
+
+template <int NT>
+struct DenseOps {   // one k-step of the dense inverse products: two spectrum values and two basis values per row tile
+  float s[2];
+  float a[NT][2];
+};
+
 // MODE 0: forward  -> log-magnitude, phase, per-clip max|log-magnitude|
 // MODE 1: adjoint of the iSTFT: sig = dL/d(wave_out); writes dL/d(log-magnitude)
 template <int MODE, int NT>
@@ -216,13 +243,18 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ lo
   int ntc[NT];   // branch-free row tiles, see stft_frames_kernel
 #pragma unroll
   for (int r = 0; r < NT; ++r) ntc[r] = 32 * (wave + 4 * r < nNT ? wave + 4 * r : nNT - 1);
-#pragma unroll 4
-  for (int f = 0; f < F; ++f) {
-    const float bv = lds[(2 * f + h) * 32 + n];
-    const float* arow = bas + (size_t)f * n_fft;
+  pipelined_steps<DenseOps<NT>>(
+      F,
+      [&](int f, DenseOps<NT>& o) {
+        o.s[0] = lds[(2 * f + h) * 32 + n];
+        const float* arow = bas + (size_t)f * n_fft;
 #pragma unroll
-    for (int r = 0; r < NT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[ntc[r]], bv, acc[r], 0, 0, 0);
-  }
+        for (int r = 0; r < NT; ++r) o.a[r][0] = arow[ntc[r]];
+      },
+      [&](const DenseOps<NT>& o) {
+#pragma unroll
+        for (int r = 0; r < NT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[r][0], o.s[0], acc[r], 0, 0, 0);
+      });
   __syncthreads();
 
   // ---- time-domain frames to LDS: ft[tl][sample], pitch n_fft+1
@@ -440,17 +472,26 @@ __global__ __launch_bounds__(64 * STFT_SYM_MAX_WAVES) void istft_sym_kernel(
   const float* bre = inv_basis + n;
   const float* bim = inv_basis + (size_t)F * n_fft + n;
   const int steps = (F + 1) / 2;
-#pragma unroll 4
-  for (int j = 0; j < steps; ++j) {
-    const int f = 2 * j + h;
-    const size_t fo = (size_t)min(f, F - 1) * n_fft;
-    const float zr = lds[(2 * f) * 32 + n], zi = lds[(2 * f + 1) * 32 + n];
+  pipelined_steps<DenseOps<NT>>(
+      steps,
+      [&](int j, DenseOps<NT>& o) {
+        const int f = 2 * j + h;
+        const size_t fo = (size_t)min(f, F - 1) * n_fft;
+        o.s[0] = lds[(2 * f) * 32 + n];
+        o.s[1] = lds[(2 * f + 1) * 32 + n];
 #pragma unroll
-    for (int r = 0; r < NT; ++r) {
-      acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bre[fo + ntc[r]], zr, acc[r][0], 0, 0, 0);
-      acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bim[fo + ntc[r]], zi, acc[r][1], 0, 0, 0);
-    }
-  }
+        for (int r = 0; r < NT; ++r) {
+          o.a[r][0] = bre[fo + ntc[r]];
+          o.a[r][1] = bim[fo + ntc[r]];
+        }
+      },
+      [&](const DenseOps<NT>& o) {
+#pragma unroll
+        for (int r = 0; r < NT; ++r) {
+          acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[r][0], o.s[0], acc[r][0], 0, 0, 0);
+          acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[r][1], o.s[1], acc[r][1], 0, 0, 0);
+        }
+      });
   __syncthreads();
 
   // E to lds[frame][p], O to lds[32 + frame][p], pitch EP (odd)
